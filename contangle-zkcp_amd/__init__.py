@@ -1,0 +1,279 @@
+"""contangle-zkcp_amd -- MI355X-native MSM / NTT backend for Contangle's prover path.
+
+Host-side mirror (Python, ctypes over the C ABI of include/zkcp_amd.h) of the upstream
+interfaces the reference's prover reaches:
+
+  ark_ec.VariableBaseMSM.multi_scalar_mul   <- ark-ec 0.3 msm/variable_base.rs
+  ark_poly.Radix2EvaluationDomain           <- ark-poly 0.3 domain/radix2/mod.rs
+  halo2.best_multiexp / halo2.best_fft      <- halo2_proofs 0.2 arithmetic.rs
+
+The compute path is the HIP library `libzkcp_amd.so` only.  There is no CPU fallback: if the
+library is missing or no MI355X is visible, `load()` / `init()` raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libzkcp_amd.so")
+
+# zk_curve_t / zk_field_t
+PALLAS, VESTA, BN254_G1, BLS12_381_G1 = 0, 1, 2, 3
+FP_PALLAS, FQ_PALLAS, FR_BN254, FR_BLS12_381 = 0, 1, 2, 3
+CURVE_NAMES = {"Pallas": PALLAS, "Vesta": VESTA, "Bn254G1": BN254_G1, "Bls381G1": BLS12_381_G1}
+FIELD_NAMES = {"PallasFp": FP_PALLAS, "PallasFq": FQ_PALLAS, "Bn254Fr": FR_BN254, "Bls381Fr": FR_BLS12_381}
+
+EXPORTS = [
+    "zk_init", "zk_shutdown", "zk_strerror", "zk_backend_info", "zk_field_limbs64", "zk_curve_base_limbs64",
+    "zk_curve_scalar_field", "zk_msm_window_bits", "zk_msm_window_count", "zk_bases_upload", "zk_bases_adopt_device",
+    "zk_bases_free", "zk_msm", "zk_msm_device", "zk_msm_last_profile", "zk_ntt", "zk_ntt_device", "zk_coset_mul",
+    "zk_coset_mul_device", "zk_field_root_of_unity", "zk_field_multiplicative_generator", "zk_field_inverse",
+    "zk_point_add", "zk_point_to_affine", "zk_fixed_base_mul_device",
+]
+
+
+class ZkError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        super().__init__("%s failed: %s (%d)" % (what, _strerror(status), status))
+
+
+class MsmOpts(ctypes.Structure):
+    _fields_ = [("window_bits", ctypes.c_int), ("window_begin", ctypes.c_int), ("window_end", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
+class MsmProfile(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_float) for k in ("digits_hist_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms",
+                                              "host_tail_ms", "total_ms")] + \
+               [(k, ctypes.c_int) for k in ("window_bits", "windows_total", "windows_done")]
+
+
+_lib = None
+
+
+def load(path=None):
+    """dlopen the HIP library (or, for the CPU test tier only, an explicitly given emulator build)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError("HIP extension %s is missing -- run `python contangle-zkcp_amd/build.py` "
+                           "(there is no CPU fallback)" % p)
+    lib = ctypes.CDLL(p)
+    lib.zk_strerror.restype = ctypes.c_char_p
+    u64, vp, i32 = ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int
+    lib.zk_bases_upload.argtypes = [i32, vp, u64, ctypes.POINTER(u64)]
+    lib.zk_bases_adopt_device.argtypes = [i32, vp, u64, ctypes.POINTER(u64)]
+    lib.zk_bases_free.argtypes = [u64]
+    lib.zk_msm.argtypes = [i32, u64, vp, u64, i32, ctypes.POINTER(MsmOpts), vp]
+    lib.zk_msm_device.argtypes = [i32, u64, vp, u64, i32, ctypes.POINTER(MsmOpts), vp, vp]
+    lib.zk_msm_last_profile.argtypes = [ctypes.POINTER(MsmProfile)]
+    lib.zk_ntt.argtypes = [i32, vp, ctypes.c_uint32, vp, i32]
+    lib.zk_ntt_device.argtypes = [i32, vp, ctypes.c_uint32, vp, i32, vp]
+    lib.zk_coset_mul.argtypes = [i32, vp, ctypes.c_uint32, vp]
+    lib.zk_coset_mul_device.argtypes = [i32, vp, ctypes.c_uint32, vp, vp]
+    lib.zk_field_root_of_unity.argtypes = [i32, ctypes.c_uint32, vp]
+    lib.zk_field_multiplicative_generator.argtypes = [i32, vp]
+    lib.zk_field_inverse.argtypes = [i32, vp, vp]
+    lib.zk_point_add.argtypes = [i32, vp, vp, vp]
+    lib.zk_point_to_affine.argtypes = [i32, vp, vp]
+    lib.zk_fixed_base_mul_device.argtypes = [i32, vp, u64, vp, vp]
+    lib.zk_msm_window_bits.argtypes = [i32, u64, i32]
+    lib.zk_msm_window_count.argtypes = [i32, u64, i32]
+    lib.zk_backend_info.argtypes = [ctypes.c_char_p, u64]
+    _lib = lib
+    return lib
+
+
+def _strerror(status):
+    return _lib.zk_strerror(status).decode() if _lib is not None else "?"
+
+
+def _check(status, what):
+    if status != 0:
+        raise ZkError(status, what)
+
+
+def init(device_id=0):
+    _check(load().zk_init(device_id), "zk_init")
+
+
+def shutdown():
+    if _lib is not None:
+        _check(_lib.zk_shutdown(), "zk_shutdown")
+
+
+def backend_info():
+    buf = ctypes.create_string_buffer(256)
+    _check(load().zk_backend_info(buf, 256), "zk_backend_info")
+    return buf.value.decode()
+
+
+def _ptr(a):
+    """numpy array -> host pointer; torch tensor -> data_ptr(); int -> as is."""
+    if isinstance(a, int):
+        return ctypes.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    return ctypes.c_void_p(a.data_ptr())
+
+
+def _np64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def curve_id(c):
+    return CURVE_NAMES[c] if isinstance(c, str) else c
+
+
+def field_id(f):
+    return FIELD_NAMES[f] if isinstance(f, str) else f
+
+
+def base_limbs(curve):
+    return load().zk_curve_base_limbs64(curve_id(curve))
+
+
+def scalar_field(curve):
+    return load().zk_curve_scalar_field(curve_id(curve))
+
+
+def root_of_unity(field, log_n):
+    out = np.zeros(4, dtype=np.uint64)
+    _check(load().zk_field_root_of_unity(field_id(field), log_n, _ptr(out)), "zk_field_root_of_unity")
+    return out
+
+
+def multiplicative_generator(field):
+    out = np.zeros(4, dtype=np.uint64)
+    _check(load().zk_field_multiplicative_generator(field_id(field), _ptr(out)), "zk_field_multiplicative_generator")
+    return out
+
+
+def field_inverse(field, a):
+    a = _np64(a)
+    out = np.zeros(4, dtype=np.uint64)
+    _check(load().zk_field_inverse(field_id(field), _ptr(a), _ptr(out)), "zk_field_inverse")
+    return out
+
+
+def point_add(curve, ja, jb):
+    ja, jb = _np64(ja), _np64(jb)
+    out = np.zeros_like(ja)
+    _check(load().zk_point_add(curve_id(curve), _ptr(ja), _ptr(jb), _ptr(out)), "zk_point_add")
+    return out
+
+
+def point_to_affine(curve, jac):
+    jac = _np64(jac)
+    out = np.zeros(2 * (jac.shape[-1] // 3), dtype=np.uint64)
+    _check(load().zk_point_to_affine(curve_id(curve), _ptr(jac), _ptr(out)), "zk_point_to_affine")
+    return out
+
+
+def msm_window_count(curve, n, window_bits=0):
+    return load().zk_msm_window_count(curve_id(curve), n, window_bits)
+
+
+def msm_window_bits(curve, n, window_bits=0):
+    return load().zk_msm_window_bits(curve_id(curve), n, window_bits)
+
+
+class Bases:
+    """Device-resident SRS / proving-key query vector (ark-groth16 0.3 ProvingKey::{a,b_g1,h,l}_query,
+    halo2 Params::g), uploaded once and reused for every proof."""
+
+    def __init__(self, curve, points=None, device_tensor=None, n=None):
+        self.curve = curve_id(curve)
+        h = ctypes.c_uint64(0)
+        if device_tensor is not None:
+            self._keep = device_tensor
+            self.n = int(n if n is not None else device_tensor.shape[0])
+            _check(load().zk_bases_adopt_device(self.curve, _ptr(device_tensor), self.n, ctypes.byref(h)),
+                   "zk_bases_adopt_device")
+        else:
+            pts = _np64(points)
+            self.n = int(pts.shape[0])
+            _check(load().zk_bases_upload(self.curve, _ptr(pts), self.n, ctypes.byref(h)), "zk_bases_upload")
+        self.handle = h.value
+
+    def free(self):
+        if self.handle:
+            _check(load().zk_bases_free(self.handle), "zk_bases_free")
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def msm(bases, scalars, montgomery=False, window_bits=0, windows=None, stream=0):
+    """sum_i scalars[i] * bases[i] -> Jacobian (X, Y, Z) as uint64[3 * limbs].
+
+    scalars: numpy uint64 [n, 4] (host) or a torch uint64/int64 tensor on the GPU (device path)."""
+    lib = load()
+    nl = lib.zk_curve_base_limbs64(bases.curve)
+    out = np.zeros(3 * nl, dtype=np.uint64)
+    opts = MsmOpts(window_bits, 0, 0, 0)
+    if windows is not None:
+        opts.window_begin, opts.window_end = windows
+    if isinstance(scalars, np.ndarray):
+        sc = _np64(scalars)
+        n = int(sc.shape[0])
+        _check(lib.zk_msm(bases.curve, bases.handle, _ptr(sc), n, int(montgomery), ctypes.byref(opts), _ptr(out)), "zk_msm")
+    else:
+        n = int(scalars.shape[0])
+        _check(lib.zk_msm_device(bases.curve, bases.handle, _ptr(scalars), n, int(montgomery), ctypes.byref(opts),
+                                 _ptr(out), ctypes.c_void_p(stream)), "zk_msm_device")
+    return out
+
+
+def msm_last_profile():
+    p = MsmProfile()
+    _check(load().zk_msm_last_profile(ctypes.byref(p)), "zk_msm_last_profile")
+    return {k: getattr(p, k) for k, _ in MsmProfile._fields_}
+
+
+def ntt(field, a, omega, scale_by_n_inv=False, stream=0):
+    """In-place size-2^k DFT with root `omega` (Montgomery); numpy (host, returns a new array) or torch GPU tensor."""
+    lib = load()
+    om = _np64(omega)
+    if isinstance(a, np.ndarray):
+        buf = _np64(a).copy()
+        n = buf.shape[0]
+        log_n = n.bit_length() - 1
+        assert n == 1 << log_n
+        _check(lib.zk_ntt(field_id(field), _ptr(buf), log_n, _ptr(om), int(scale_by_n_inv)), "zk_ntt")
+        return buf
+    n = int(a.shape[0])
+    log_n = n.bit_length() - 1
+    assert n == 1 << log_n
+    _check(lib.zk_ntt_device(field_id(field), _ptr(a), log_n, _ptr(om), int(scale_by_n_inv), ctypes.c_void_p(stream)),
+           "zk_ntt_device")
+    return a
+
+
+def coset_mul(field, a, g, stream=0):
+    lib = load()
+    gm = _np64(g)
+    if isinstance(a, np.ndarray):
+        buf = _np64(a).copy()
+        log_n = buf.shape[0].bit_length() - 1
+        _check(lib.zk_coset_mul(field_id(field), _ptr(buf), log_n, _ptr(gm)), "zk_coset_mul")
+        return buf
+    log_n = int(a.shape[0]).bit_length() - 1
+    _check(lib.zk_coset_mul_device(field_id(field), _ptr(a), log_n, _ptr(gm), ctypes.c_void_p(stream)), "zk_coset_mul_device")
+    return a
+
+
+def fixed_base_mul_device(curve, d_scalars, d_out, n, stream=0):
+    _check(load().zk_fixed_base_mul_device(curve_id(curve), _ptr(d_scalars), n, _ptr(d_out), ctypes.c_void_p(stream)),
+           "zk_fixed_base_mul_device")
+
+
+from . import ark, halo2  # noqa: E402,F401  (interface mirrors)

@@ -1,0 +1,229 @@
+// Short-Weierstrass (a = 0) group arithmetic for the MSM path: Pallas, Vesta, BN254 G1,
+// BLS12-381 G1.  Bucket accumulators use extended Jacobian "XYZZ" coordinates
+// (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2): a mixed add is 8M+2S with no inversion and, unlike
+// the Jacobian form ark-ec 0.3 / pasta use on the CPU, needs no squaring of Z.  Results
+// leave the library as Jacobian (X, Y, Z) -- the representation of ark-ec 0.3
+// `GroupProjective` and pasta_curves 0.4 `Ep/Eq` -- so a Rust shim can rebuild the
+// caller's type limb for limb.
+//
+// Affine points are (x, y) Montgomery; infinity is encoded as (0, 0), which is never on
+// y^2 = x^3 + b for b != 0.
+#pragma once
+#include "zk_field.h"
+
+namespace zk {
+
+template <class C>
+struct Affine {
+    Fe<typename C::Fq> x, y;
+};
+template <class C>
+struct XYZZ {
+    Fe<typename C::Fq> x, y, zz, zzz;
+};
+template <class C>
+struct Jacobian {
+    Fe<typename C::Fq> x, y, z;
+};
+
+template <class C>
+ZK_HD bool aff_is_inf(const Affine<C>& p) {
+    uint32_t o = 0;
+    ZK_UNROLL
+    for (int i = 0; i < C::Fq::N; i++) o |= p.x.v[i] | p.y.v[i];
+    return o == 0;
+}
+template <class C>
+ZK_HD void xyzz_set_inf(XYZZ<C>& p) {
+    fe_zero(p.x);
+    fe_zero(p.y);
+    fe_zero(p.zz);
+    fe_zero(p.zzz);
+}
+template <class C>
+ZK_HD bool xyzz_is_inf(const XYZZ<C>& p) {
+    return fe_is_zero(p.zz);
+}
+template <class C>
+ZK_HD void xyzz_from_affine(XYZZ<C>& r, const Affine<C>& p) {
+    if (aff_is_inf(p)) {
+        xyzz_set_inf(r);
+        return;
+    }
+    r.x = p.x;
+    r.y = p.y;
+    fe_one(r.zz);
+    fe_one(r.zzz);
+}
+
+// mdbl-2008-s-1: r = 2*(affine p), p != inf
+template <class C>
+ZK_HD void xyzz_dbl_affine(XYZZ<C>& r, const Affine<C>& p) {
+    using F = typename C::Fq;
+    Fe<F> u, v, w, s, m, t;
+    fe_dbl(u, p.y);
+    fe_sqr(v, u);
+    fe_mul(w, u, v);
+    fe_mul(s, p.x, v);
+    fe_sqr(t, p.x);
+    fe_dbl(m, t);
+    fe_add(m, m, t);  // 3 x^2
+    fe_sqr(r.x, m);
+    fe_sub(r.x, r.x, s);
+    fe_sub(r.x, r.x, s);
+    fe_sub(t, s, r.x);
+    fe_mul(t, m, t);
+    fe_mul(u, w, p.y);
+    fe_sub(r.y, t, u);
+    r.zz = v;
+    r.zzz = w;
+}
+
+// dbl-2008-s-1: p = 2p
+template <class C>
+ZK_HD void xyzz_dbl(XYZZ<C>& p) {
+    using F = typename C::Fq;
+    if (xyzz_is_inf(p)) return;
+    Fe<F> u, v, w, s, m, t, x3;
+    fe_dbl(u, p.y);
+    fe_sqr(v, u);
+    fe_mul(w, u, v);
+    fe_mul(s, p.x, v);
+    fe_sqr(t, p.x);
+    fe_dbl(m, t);
+    fe_add(m, m, t);
+    fe_sqr(x3, m);
+    fe_sub(x3, x3, s);
+    fe_sub(x3, x3, s);
+    fe_sub(t, s, x3);
+    fe_mul(t, m, t);
+    fe_mul(u, w, p.y);
+    fe_sub(p.y, t, u);
+    p.x = x3;
+    fe_mul(p.zz, v, p.zz);
+    fe_mul(p.zzz, w, p.zzz);
+}
+
+// madd-2008-s: acc += (affine q), all special cases handled
+template <class C>
+ZK_HD void xyzz_add_mixed(XYZZ<C>& acc, const Affine<C>& q) {
+    using F = typename C::Fq;
+    if (aff_is_inf(q)) return;
+    if (xyzz_is_inf(acc)) {
+        acc.x = q.x;
+        acc.y = q.y;
+        fe_one(acc.zz);
+        fe_one(acc.zzz);
+        return;
+    }
+    Fe<F> p, r, pp, ppp, qq, t;
+    fe_mul(p, q.x, acc.zz);
+    fe_mul(r, q.y, acc.zzz);
+    fe_sub(p, p, acc.x);
+    fe_sub(r, r, acc.y);
+    if (fe_is_zero(p)) {
+        if (fe_is_zero(r)) {
+            xyzz_dbl_affine(acc, q);  // same point
+        } else {
+            xyzz_set_inf(acc);  // opposite points
+        }
+        return;
+    }
+    fe_sqr(pp, p);
+    fe_mul(ppp, p, pp);
+    fe_mul(qq, acc.x, pp);
+    fe_sqr(acc.x, r);
+    fe_sub(acc.x, acc.x, ppp);
+    fe_sub(acc.x, acc.x, qq);
+    fe_sub(acc.x, acc.x, qq);
+    fe_sub(t, qq, acc.x);
+    fe_mul(t, r, t);
+    fe_mul(acc.y, acc.y, ppp);
+    fe_sub(acc.y, t, acc.y);
+    fe_mul(acc.zz, acc.zz, pp);
+    fe_mul(acc.zzz, acc.zzz, ppp);
+}
+
+// add-2008-s: acc += q (both XYZZ), all special cases handled
+template <class C>
+ZK_HD void xyzz_add(XYZZ<C>& acc, const XYZZ<C>& q) {
+    using F = typename C::Fq;
+    if (xyzz_is_inf(q)) return;
+    if (xyzz_is_inf(acc)) {
+        acc = q;
+        return;
+    }
+    Fe<F> u1, u2, s1, s2, p, r, pp, ppp, qq, t;
+    fe_mul(u1, acc.x, q.zz);
+    fe_mul(u2, q.x, acc.zz);
+    fe_mul(s1, acc.y, q.zzz);
+    fe_mul(s2, q.y, acc.zzz);
+    fe_sub(p, u2, u1);
+    fe_sub(r, s2, s1);
+    if (fe_is_zero(p)) {
+        if (fe_is_zero(r)) {
+            xyzz_dbl(acc);
+        } else {
+            xyzz_set_inf(acc);
+        }
+        return;
+    }
+    fe_sqr(pp, p);
+    fe_mul(ppp, p, pp);
+    fe_mul(qq, u1, pp);
+    fe_sqr(acc.x, r);
+    fe_sub(acc.x, acc.x, ppp);
+    fe_sub(acc.x, acc.x, qq);
+    fe_sub(acc.x, acc.x, qq);
+    fe_sub(t, qq, acc.x);
+    fe_mul(t, r, t);
+    fe_mul(s1, s1, ppp);
+    fe_sub(acc.y, t, s1);
+    fe_mul(acc.zz, acc.zz, q.zz);
+    fe_mul(acc.zz, acc.zz, pp);
+    fe_mul(acc.zzz, acc.zzz, q.zzz);
+    fe_mul(acc.zzz, acc.zzz, ppp);
+}
+
+// XYZZ -> Jacobian: (X*ZZ, Y*ZZZ, ZZ) satisfies x = X'/Z'^2, y = Y'/Z'^3.  Identity -> (0, R, 0)
+// (ark-ec 0.3 `GroupProjective::zero()` = (0, 1, 0)).
+template <class C>
+ZK_HD void xyzz_to_jacobian(Jacobian<C>& r, const XYZZ<C>& p) {
+    if (xyzz_is_inf(p)) {
+        fe_zero(r.x);
+        fe_one(r.y);
+        fe_zero(r.z);
+        return;
+    }
+    fe_mul(r.x, p.x, p.zz);
+    fe_mul(r.y, p.y, p.zzz);
+    r.z = p.zz;
+}
+
+// XYZZ -> affine (host-side: one Fermat inversion).  Identity -> (0, 0)
+template <class C>
+ZK_HD void xyzz_to_affine(Affine<C>& r, const XYZZ<C>& p) {
+    using F = typename C::Fq;
+    if (xyzz_is_inf(p)) {
+        fe_zero(r.x);
+        fe_zero(r.y);
+        return;
+    }
+    Fe<F> izzz, izz, t;
+    fe_inv(izzz, p.zzz);       // 1/z^3
+    fe_mul(t, izzz, p.zz);     // 1/z
+    fe_sqr(izz, t);            // 1/z^2
+    fe_mul(r.x, p.x, izz);
+    fe_mul(r.y, p.y, izzz);
+}
+
+template <class C>
+ZK_HD void aff_neg_if(Affine<C>& p, bool neg) {
+    // y -> p - y when neg (y != 0 for any finite point of odd-order groups; (0,0) stays (0,0) via the mask)
+    Fe<typename C::Fq> ny;
+    fe_neg(ny, p.y);
+    ZK_UNROLL
+    for (int i = 0; i < C::Fq::N; i++) p.y.v[i] = neg ? ny.v[i] : p.y.v[i];
+}
+
+}  // namespace zk

@@ -1,0 +1,209 @@
+// Montgomery prime-field arithmetic on 32-bit limbs for gfx950 (and the host).
+//
+// Memory layout is bit-identical to ark-ff 0.3 `Fp256/Fp384` and pasta_curves 0.4
+// `Fp/Fq` (little-endian u64 limbs, Montgomery form, R = 2^(64*limbs64)): 8 (or 12)
+// little-endian u32 words are the same bytes.  The reference reaches these types only
+// through `Groth16::<Bls12_381>::prove` (lib/src/zk/verifiable_encryption.rs:92 and
+// siblings); the arithmetic itself is upstream.
+//
+// CDNA4 has no 64x64 multiplier: products are built from 32x32->64 MADs
+// (`v_mad_u64_u32`), so the natural limb is 32 bits.  All loops are fully unrolled
+// over compile-time limb counts so that elements live in VGPRs and modulus words fold
+// to literals (for the Pasta primes five of the eight words are 0 or 1 and vanish).
+#pragma once
+#include <stdint.h>
+
+#include "zk_params.h"
+
+#if defined(__HIPCC__)
+#define ZK_HD __host__ __device__ inline __attribute__((always_inline))
+#define ZK_UNROLL _Pragma("unroll")
+#else
+#define ZK_HD inline __attribute__((always_inline))
+#define ZK_UNROLL
+#endif
+
+namespace zk {
+
+template <class P>
+struct alignas(16) Fe {
+    uint32_t v[P::N];
+};
+
+template <class P>
+ZK_HD void fe_zero(Fe<P>& r) {
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) r.v[i] = 0;
+}
+template <class P>
+ZK_HD void fe_one(Fe<P>& r) {
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) r.v[i] = P::R[i];
+}
+template <class P>
+ZK_HD bool fe_is_zero(const Fe<P>& a) {
+    uint32_t o = 0;
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) o |= a.v[i];
+    return o == 0;
+}
+template <class P>
+ZK_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
+    uint32_t o = 0;
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+
+// t -= p if t >= p  (t < 2p on entry)
+template <class P>
+ZK_HD void fe_reduce_once(uint32_t* t) {
+    uint32_t d[P::N];
+    uint64_t br = 0;
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) {
+        uint64_t x = (uint64_t)t[i] - P::P[i] - br;
+        d[i] = (uint32_t)x;
+        br = (x >> 32) & 1;
+    }
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) t[i] = br ? t[i] : d[i];
+}
+
+template <class P>
+ZK_HD void fe_add(Fe<P>& r, const Fe<P>& a, const Fe<P>& b) {
+    uint32_t t[P::N];
+    uint64_t c = 0;
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) {
+        c += (uint64_t)a.v[i] + b.v[i];
+        t[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    // every supported modulus leaves a spare top bit: a + b < 2p < 2^(32N), no carry out
+    fe_reduce_once<P>(t);
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) r.v[i] = t[i];
+}
+
+template <class P>
+ZK_HD void fe_sub(Fe<P>& r, const Fe<P>& a, const Fe<P>& b) {
+    uint32_t t[P::N];
+    uint64_t br = 0;
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) {
+        uint64_t x = (uint64_t)a.v[i] - b.v[i] - br;
+        t[i] = (uint32_t)x;
+        br = (x >> 32) & 1;
+    }
+    const uint32_t mask = (uint32_t)0 - (uint32_t)br;
+    uint64_t c = 0;
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) {
+        c += (uint64_t)t[i] + (P::P[i] & mask);
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+}
+
+template <class P>
+ZK_HD void fe_neg(Fe<P>& r, const Fe<P>& a) {
+    Fe<P> z;
+    fe_zero(z);
+    fe_sub(r, z, a);
+}
+template <class P>
+ZK_HD void fe_dbl(Fe<P>& r, const Fe<P>& a) {
+    fe_add(r, a, a);
+}
+
+// Montgomery product r = a*b*R^-1 mod p (CIOS).  Every supported modulus has its top
+// bit clear, so the running value stays below 2p < 2^(32N) and the (N+2)-th word of
+// textbook CIOS is never needed.
+template <class P>
+ZK_HD void fe_mul(Fe<P>& r, const Fe<P>& a, const Fe<P>& b) {
+    constexpr int N = P::N;
+    uint32_t t[N];
+    ZK_UNROLL
+    for (int i = 0; i < N; i++) t[i] = 0;
+    ZK_UNROLL
+    for (int i = 0; i < N; i++) {
+        uint64_t c = 0;
+        const uint32_t bi = b.v[i];
+        ZK_UNROLL
+        for (int j = 0; j < N; j++) {
+            uint64_t x = (uint64_t)a.v[j] * bi + t[j] + c;
+            t[j] = (uint32_t)x;
+            c = x >> 32;
+        }
+        const uint32_t tn = (uint32_t)c;
+        const uint32_t m = t[0] * P::INV;
+        uint64_t x = (uint64_t)m * P::P[0] + t[0];
+        c = x >> 32;
+        ZK_UNROLL
+        for (int j = 1; j < N; j++) {
+            x = (uint64_t)m * P::P[j] + t[j] + c;
+            t[j - 1] = (uint32_t)x;
+            c = x >> 32;
+        }
+        t[N - 1] = (uint32_t)((uint64_t)tn + c);
+    }
+    fe_reduce_once<P>(t);
+    ZK_UNROLL
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+}
+
+template <class P>
+ZK_HD void fe_sqr(Fe<P>& r, const Fe<P>& a) {
+    fe_mul(r, a, a);
+}
+
+// canonical <-> Montgomery (ark-ff from_repr / into_repr; pasta from_repr / to_repr)
+template <class P>
+ZK_HD void fe_to_mont(Fe<P>& r, const Fe<P>& a) {
+    Fe<P> r2;
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) r2.v[i] = P::R2[i];
+    fe_mul(r, a, r2);
+}
+template <class P>
+ZK_HD void fe_from_mont(Fe<P>& r, const Fe<P>& a) {
+    Fe<P> one;
+    fe_zero(one);
+    one.v[0] = 1;
+    fe_mul(r, a, one);
+}
+
+// r = a^e for a 64-bit exponent (square-and-multiply, LSB first)
+template <class P>
+ZK_HD void fe_pow_u64(Fe<P>& r, const Fe<P>& a, uint64_t e) {
+    Fe<P> acc, base = a;
+    fe_one(acc);
+    while (e) {
+        if (e & 1) fe_mul(acc, acc, base);
+        fe_sqr(base, base);
+        e >>= 1;
+    }
+    r = acc;
+}
+
+// Fermat inverse a^(p-2) (host-side use: one-off normalisations); 0 -> 0
+template <class P>
+ZK_HD void fe_inv(Fe<P>& r, const Fe<P>& a) {
+    uint32_t e[P::N];
+    uint64_t br = 2;  // e = p - 2 with borrow propagation (the Pasta primes have low word 1)
+    for (int i = 0; i < P::N; i++) {
+        uint64_t x = (uint64_t)P::P[i] - br;
+        e[i] = (uint32_t)x;
+        br = (x >> 32) & 1;
+    }
+    Fe<P> acc, base = a;
+    fe_one(acc);
+    for (int i = 0; i < 32 * P::N; i++) {
+        if ((e[i / 32] >> (i % 32)) & 1) fe_mul(acc, acc, base);
+        fe_sqr(base, base);
+    }
+    r = acc;
+}
+
+}  // namespace zk

@@ -1,0 +1,424 @@
+// HIP kernels for the MSM / NTT hot path (gfx950).  Replaces, behind the C ABI of
+// include/zkcp_amd.h, the upstream CPU routines the reference reaches through
+// `Groth16::<Bls12_381>::prove` (lib/src/zk/verifiable_encryption.rs:92, encryption.rs:76,
+// sample_entries.rs:86, property.rs:133):
+//   ark-ec 0.3   msm/variable_base.rs   VariableBaseMSM::multi_scalar_mul      
+//   ark-poly 0.3 domain/radix2/fft.rs   Radix2EvaluationDomain::*fft_in_place  
+//   halo2_proofs 0.2 arithmetic.rs      best_multiexp / best_fft               
+// Design notes (data layout, roofline per kernel) are in DESIGN.md.
+#pragma once
+#include "zk_rt.h"
+// (zk_rt.h first: it brings in the HIP runtime or the test emulator)
+#include "zk_curve.h"
+
+namespace zk {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) {
+    return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
+}
+
+// acc = prod_{k : bit k of e set} tbl[k]   (tbl[k] = base^(2^k), Montgomery)
+template <class F>
+__device__ __forceinline__ void pow_from_table(Fe<F>& acc, const Fe<F>* __restrict__ tbl, uint64_t e, int nbits) {
+    fe_one(acc);
+    for (int k = 0; k < nbits; k++) {
+        if ((e >> k) & 1) {
+            Fe<F> t = tbl[k];
+            fe_mul(acc, acc, t);
+        }
+    }
+}
+
+// out[i] = base^i, i < count   (twiddle table: base = omega, count = n/2)
+template <class F>
+__global__ void pow_table_kernel(Fe<F>* __restrict__ out, const Fe<F>* __restrict__ tbl, uint64_t count, int nbits) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fe<F> acc;
+    pow_from_table(acc, tbl, i, nbits);
+    out[i] = acc;
+}
+
+// a[i] *= g^i   (ark-poly 0.3 Radix2EvaluationDomain::distribute_powers; halo2 coset shift by ZETA powers)
+template <class F>
+__global__ void coset_mul_kernel(Fe<F>* __restrict__ a, const Fe<F>* __restrict__ tbl, uint64_t count, int nbits) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fe<F> acc, x = a[i];
+    pow_from_table(acc, tbl, i, nbits);
+    fe_mul(x, x, acc);
+    a[i] = x;
+}
+
+// ------------------------------------------------------------------------------------------
+// NTT: mixed-radix decimation-in-frequency, one kernel per pass, natural order in and out.
+//
+// n = 2^L is split into P digits of widths r_1..r_P.  Input index n = (n_1 | n_2 | .. | n_P)
+// (n_1 most significant); after pass p the buffer holds, at position (k_1..k_p | n_{p+1}..n_P),
+//   Y_p = DFT over digit p of Y_{p-1}, times the inter-pass twiddle omega^(M_p * k_p * n'),
+// with M_p = 2^(r_1+..+r_{p-1}) and n' the value of the remaining digits.  The last pass stores
+// to the digit-reversed (= natural) address k = k_1 + M_2 k_2 + .. + M_P k_P.
+//
+// One workgroup owns an R x T tile (R = 2^r_p points of the radix axis, T adjacent columns so
+// that every global access is a run of T*32 B); the R-point DFTs run as radix-2 butterflies in
+// LDS (limb-major "SoA" so unit-stride lanes hit distinct banks), twiddles come from one table
+// tw[i] = omega^i, i < n/2, shared by the inner butterflies (stride n/R) and the inter-pass step.
+// ------------------------------------------------------------------------------------------
+struct NttPass {
+    int logn;   // L
+    int log_m;  // log2 M_p
+    int log_r;  // r_p
+    int log_t;  // log2 T
+    int last;   // final pass (S_p == 1): digit-reversed store, optional scaling
+    int scale;  // multiply outputs by `scale` (n^-1 for inverse transforms)
+    int nd;     // P
+    int rd[4];  // r_1..r_P
+};
+
+template <class F>
+__device__ __forceinline__ void tw_get(Fe<F>& w, const Fe<F>* __restrict__ tw, uint64_t e, uint64_t half) {
+    // omega^e for e < n, from the half table: omega^(n/2) = -1
+    if (e >= half) {
+        Fe<F> t = tw[e - half];
+        fe_neg(w, t);
+    } else {
+        w = tw[e];
+    }
+}
+
+template <class F>
+__global__ void ntt_pass_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out, const Fe<F>* __restrict__ tw,
+                                NttPass A, Fe<F> scale) {
+    ZK_DYN_SHARED(uint32_t, lds);
+    constexpr int NL = F::N;
+    const uint32_t R = 1u << A.log_r, T = 1u << A.log_t, RT = R * T;
+    const int log_np = A.logn - A.log_m;
+    const int log_s = log_np - A.log_r;
+    const uint64_t half = (A.logn > 0) ? (1ull << (A.logn - 1)) : 1ull;
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+
+    uint64_t base, stride_j, stride_t;
+    uint64_t nprime0 = 0, out_fixed = 0;  // last pass: k_1 base + reversed middle digits
+    if (!A.last) {
+        const uint64_t tiles_per_a = (1ull << log_s) >> A.log_t;
+        const uint64_t a = blockIdx.x / tiles_per_a;
+        nprime0 = (blockIdx.x % tiles_per_a) << A.log_t;
+        base = (a << log_np) + nprime0;
+        stride_j = 1ull << log_s;
+        stride_t = 1;
+    } else if (A.nd == 1) {
+        base = 0;
+        stride_j = 1;
+        stride_t = 0;
+    } else {
+        const int log_rest = A.log_m - A.rd[0];
+        const uint64_t rest = blockIdx.x & ((1ull << log_rest) - 1);
+        const uint64_t k1_0 = ((uint64_t)blockIdx.x >> log_rest) << A.log_t;
+        base = ((k1_0 << log_rest) + rest) << A.log_r;
+        stride_j = 1;
+        stride_t = 1ull << (log_rest + A.log_r);
+        // reverse the middle digits k_2..k_{P-1} of `rest` into their natural weights M_p
+        uint64_t rr = rest, acc = 0;
+        int logm = A.log_m;
+        for (int p = A.nd - 2; p >= 1; p--) {
+            logm -= A.rd[p];
+            acc += (rr & ((1ull << A.rd[p]) - 1)) << logm;
+            rr >>= A.rd[p];
+        }
+        out_fixed = k1_0 + acc;
+    }
+    // LDS position of tile element (j, t): the fast axis follows the contiguous global axis
+    auto pos = [&](uint32_t j, uint32_t t) -> uint32_t { return A.last ? (t << A.log_r) + j : (j << A.log_t) + t; };
+
+    // ---- load tile
+    for (uint32_t e = tid; e < RT; e += nth) {
+        uint32_t j, t;
+        if (A.last) {
+            j = e & (R - 1);
+            t = e >> A.log_r;
+        } else {
+            t = e & (T - 1);
+            j = e >> A.log_t;
+        }
+        Fe<F> x = in[base + j * stride_j + t * stride_t];
+        const uint32_t p = pos(j, t);
+        ZK_UNROLL
+        for (int l = 0; l < NL; l++) lds[l * RT + p] = x.v[l];
+    }
+    __syncthreads();
+
+    // ---- radix-2 DIF butterflies over the R axis (output in bit-reversed LDS order)
+    const uint32_t nbf = RT >> 1;
+    for (int lg = A.log_r - 1; lg >= 0; lg--) {
+        const uint32_t g = 1u << lg;
+        for (uint32_t b = tid; b < nbf; b += nth) {
+            uint32_t q, t;
+            if (A.last) {
+                q = b & ((R >> 1) - 1);
+                t = b >> (A.log_r - 1);
+            } else {
+                t = b & (T - 1);
+                q = b >> A.log_t;
+            }
+            const uint32_t j = ((q >> lg) << (lg + 1)) | (q & (g - 1));
+            const uint32_t p0 = pos(j, t), p1 = pos(j + g, t);
+            Fe<F> u, w, s, d;
+            ZK_UNROLL
+            for (int l = 0; l < NL; l++) {
+                u.v[l] = lds[l * RT + p0];
+                w.v[l] = lds[l * RT + p1];
+            }
+            fe_add(s, u, w);
+            fe_sub(d, u, w);
+            if (lg > 0) {
+                const uint64_t e = (uint64_t)(q & (g - 1)) << (A.logn - 1 - lg);
+                Fe<F> twv = tw[e];
+                fe_mul(d, d, twv);
+            }
+            ZK_UNROLL
+            for (int l = 0; l < NL; l++) {
+                lds[l * RT + p0] = s.v[l];
+                lds[l * RT + p1] = d.v[l];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- store: inter-pass twiddle (non-last) or digit-reversed natural address (last)
+    for (uint32_t e = tid; e < RT; e += nth) {
+        const uint32_t t = e & (T - 1);
+        const uint32_t k = e >> A.log_t;
+        const uint32_t p = pos(bitrev32(k, A.log_r), t);
+        Fe<F> x;
+        ZK_UNROLL
+        for (int l = 0; l < NL; l++) x.v[l] = lds[l * RT + p];
+        if (!A.last) {
+            const uint64_t ex = ((uint64_t)k * (nprime0 + t)) << A.log_m;
+            if (ex != 0) {
+                Fe<F> w;
+                tw_get(w, tw, ex, half);
+                fe_mul(x, x, w);
+            }
+            out[base + (uint64_t)k * stride_j + t] = x;
+        } else {
+            if (A.scale) fe_mul(x, x, scale);
+            out[out_fixed + t + ((uint64_t)k << A.log_m)] = x;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MSM: signed-digit Pippenger.
+//   1. msm_hist_kernel     scalar -> signed c-bit digits, per-(window, bucket) counts
+//   2. msm_scan_kernel     exclusive prefix over the counts
+//   3. msm_scatter_kernel  counting-sort scatter of (point index | sign) by (window, bucket)
+//   4. msm_accumulate_kernel  one lane per bucket, XYZZ mixed adds over its sorted slice
+//   5. msm_reduce_kernel   sum_b b*B_b by slices: X_t = W_t + [t*L] S_t
+//   6. msm_sum_kernel      per-window tree sums of X_t
+//   host: <= a few points per window, Horner over windows (c doublings each).
+// Digits are in [-2^(c-1), 2^(c-1)]; bucket b in 1..2^(c-1) holds sum of (+-)P_i with |digit| = b.
+// ------------------------------------------------------------------------------------------
+struct MsmShape {
+    uint32_t n;
+    int c;            // window bits
+    int w0, nw;       // this call accumulates windows [w0, w0 + nw) of the scalar (window-range sharding)
+    uint32_t nbk;     // buckets per window = 2^(c-1)
+    int mont;         // scalars arrive in Montgomery form (halo2) rather than canonical (ark BigInt)
+};
+
+template <int N>
+__device__ __forceinline__ uint32_t word_at(const uint32_t (&s)[N], int idx) {
+    uint32_t v = 0;
+    ZK_UNROLL
+    for (int k = 0; k < N; k++) v = (idx == k) ? s[k] : v;
+    return v;
+}
+template <int N>
+__device__ __forceinline__ uint32_t bits_at(const uint32_t (&s)[N], int start, int c) {
+    const int idx = start >> 5, off = start & 31;
+    uint64_t v = word_at<N>(s, idx);
+    v |= (uint64_t)word_at<N>(s, idx + 1) << 32;  // idx+1 == N selects 0
+    return (uint32_t)(v >> off) & ((1u << c) - 1);
+}
+
+template <class Fr>
+__device__ __forceinline__ void load_scalar(uint32_t (&s)[Fr::N], const Fe<Fr>* __restrict__ scalars, uint32_t i, int mont) {
+    Fe<Fr> x = scalars[i];
+    if (mont) fe_from_mont(x, x);
+    ZK_UNROLL
+    for (int k = 0; k < Fr::N; k++) s[k] = x.v[k];
+}
+
+// visits every non-zero digit of windows [w0, w0+nw): f(window_local, bucket_index(0-based), negative)
+template <class Fr, class Fn>
+__device__ __forceinline__ void for_each_digit(const uint32_t (&s)[Fr::N], const MsmShape& sh, Fn&& f) {
+    uint32_t carry = 0;
+    for (int w = 0; w < sh.w0 + sh.nw; w++) {
+        uint32_t raw = bits_at<Fr::N>(s, w * sh.c, sh.c) + carry;
+        bool neg = raw > sh.nbk;
+        uint32_t mag = neg ? (1u << sh.c) - raw : raw;
+        carry = neg ? 1u : 0u;
+        if (w >= sh.w0 && mag != 0) f(w - sh.w0, mag - 1, neg);
+    }
+}
+
+template <class C>
+__global__ void msm_hist_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh, uint32_t* __restrict__ counts) {
+    using Fr = typename C::Fr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sh.n) return;
+    uint32_t s[Fr::N];
+    load_scalar<Fr>(s, scalars, i, sh.mont);
+    for_each_digit<Fr>(s, sh, [&](int w, uint32_t b, bool) { atomicAdd(&counts[(uint32_t)w * sh.nbk + b], 1u); });
+}
+
+// offs[i] = sum_{k<i} counts[k]; single workgroup of 1024 lanes
+__global__ void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t m) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (m + 1023) / 1024;
+    const uint32_t lo = tid * per < m ? tid * per : m;
+    const uint32_t hi = lo + per < m ? lo + per : m;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += counts[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        offs[i] = run;
+        run += counts[i];
+    }
+}
+
+template <class C>
+__global__ void msm_scatter_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ offs,
+                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+    using Fr = typename C::Fr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sh.n) return;
+    uint32_t s[Fr::N];
+    load_scalar<Fr>(s, scalars, i, sh.mont);
+    for_each_digit<Fr>(s, sh, [&](int w, uint32_t b, bool neg) {
+        const uint32_t gb = (uint32_t)w * sh.nbk + b;
+        const uint32_t p = offs[gb] + atomicAdd(&cursor[gb], 1u);
+        sorted[p] = i | (neg ? 0x80000000u : 0u);
+    });
+}
+
+template <class C>
+__global__ void msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                      const uint32_t* __restrict__ offs, const uint32_t* __restrict__ counts,
+                                      XYZZ<C>* __restrict__ buckets, uint32_t nbuckets) {
+    const uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gb >= nbuckets) return;
+    const uint32_t start = offs[gb], cnt = counts[gb];
+    XYZZ<C> acc;
+    xyzz_set_inf(acc);
+    for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t e = sorted[start + k];
+        Affine<C> p = bases[e & 0x7fffffffu];
+        aff_neg_if(p, (e >> 31) != 0);
+        xyzz_add_mixed(acc, p);
+    }
+    buckets[gb] = acc;
+}
+
+// slice t of window w covers bucket indices [t*L, (t+1)*L) (weights index+1):
+//   X_t = sum_l (l+1) B_{tL+l} + [t*L] * sum_l B_{tL+l}
+template <class C>
+__global__ void msm_reduce_kernel(const XYZZ<C>* __restrict__ buckets, XYZZ<C>* __restrict__ out, uint32_t nbk, uint32_t L,
+                                  uint32_t slices_per_window, uint32_t nslices) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt >= nslices) return;
+    const uint32_t w = gt / slices_per_window, t = gt % slices_per_window;
+    XYZZ<C> run, wsum;
+    xyzz_set_inf(run);
+    xyzz_set_inf(wsum);
+    for (int l = (int)L - 1; l >= 0; l--) {
+        const uint32_t i = t * L + (uint32_t)l;
+        if (i < nbk) {
+            XYZZ<C> b = buckets[(uint64_t)w * nbk + i];
+            xyzz_add(run, b);
+        }
+        xyzz_add(wsum, run);
+    }
+    // wsum += [t*L] run   (MSB-first double-and-add on a <= 31-bit multiplier)
+    const uint32_t m = t * L;
+    if (m != 0 && !xyzz_is_inf(run)) {
+        XYZZ<C> acc;
+        xyzz_set_inf(acc);
+        for (int bit = 31 - __clz(m); bit >= 0; bit--) {
+            xyzz_dbl(acc);
+            if ((m >> bit) & 1) xyzz_add(acc, run);
+        }
+        xyzz_add(wsum, acc);
+    }
+    out[gt] = wsum;
+}
+
+// out[s*per_out + o] = sum of in[s*per_in + o*chunk .. +chunk), chunk = 256*E; one workgroup (256 lanes) per output
+template <class C>
+__global__ void msm_sum_kernel(const XYZZ<C>* __restrict__ in, XYZZ<C>* __restrict__ out, uint32_t per_in, uint32_t per_out,
+                               uint32_t E) {
+    __shared__ XYZZ<C> sh[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t s = blockIdx.x / per_out, o = blockIdx.x % per_out;
+    const uint32_t chunk = 256 * E;
+    const uint32_t lo = o * chunk;
+    XYZZ<C> acc;
+    xyzz_set_inf(acc);
+    for (uint32_t k = 0; k < E; k++) {
+        const uint32_t i = lo + k * 256 + tid;
+        if (i < per_in && i < lo + chunk) {
+            XYZZ<C> b = in[(uint64_t)s * per_in + i];
+            xyzz_add(acc, b);
+        }
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (tid < d) {
+            XYZZ<C> b = sh[tid + d];
+            xyzz_add(acc, b);
+            sh[tid] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[(uint64_t)s * per_out + o] = acc;
+}
+
+// out[i] = [k_i] G in affine form (k canonical).  Used to build seeded test / bench bases
+// (P_i = [k_i]G) and as the building block of fixed-base setup work.
+template <class C>
+__global__ void fixed_base_mul_kernel(const Fe<typename C::Fr>* __restrict__ scalars, Affine<C>* __restrict__ out, uint32_t n) {
+    using Fr = typename C::Fr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<Fr> k = scalars[i];
+    Affine<C> g;
+    ZK_UNROLL
+    for (int l = 0; l < C::Fq::N; l++) {
+        g.x.v[l] = C::GX[l];
+        g.y.v[l] = C::GY[l];
+    }
+    XYZZ<C> acc;
+    xyzz_set_inf(acc);
+    for (int bit = 32 * Fr::N - 1; bit >= 0; bit--) {
+        xyzz_dbl(acc);
+        if ((word_at<Fr::N>(k.v, bit >> 5) >> (bit & 31)) & 1) xyzz_add_mixed(acc, g);
+    }
+    Affine<C> r;
+    xyzz_to_affine(r, acc);
+    out[i] = r;
+}
+
+}  // namespace zk

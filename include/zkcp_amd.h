@@ -1,0 +1,135 @@
+/*
+ * zkcp_amd -- C ABI of the MI355X (gfx950) MSM / NTT proving backend.
+ *
+ * The reference (nulltea/contangle-zkcp) has no FFI or plugin seam of its own: its prover
+ * calls `Groth16::<Bls12_381>::prove` (lib/src/zk/verifiable_encryption.rs:92,
+ * lib/src/zk/encryption.rs:76, lib/src/zk/sample_entries.rs:86, lib/src/zk/property.rs:133)
+ * and all MSM/NTT arithmetic happens inside un-vendored crates.  The entry
+ * points below are therefore exactly what a `[patch.crates-io]` shim of those crates binds:
+ *
+ *   zk_msm / zk_msm_device      <-  ark-ec 0.3  msm/variable_base.rs  VariableBaseMSM::multi_scalar_mul
+ *                                   halo2_proofs 0.2  arithmetic.rs   best_multiexp
+ *   zk_ntt / zk_ntt_device      <-  ark-poly 0.3  domain/radix2/{mod,fft}.rs  Radix2EvaluationDomain::{fft,ifft}_in_place
+ *                                   halo2_proofs 0.2  arithmetic.rs   best_fft
+ *   zk_coset_mul[_device]       <-  ark-poly 0.3  Radix2EvaluationDomain::distribute_powers (coset_fft / coset_ifft)
+ *                                   halo2_proofs 0.2  poly/domain.rs  EvaluationDomain::distribute_powers_zeta
+ *   zk_bases_*                  <-  residency of ark-groth16 0.3 `ProvingKey` query vectors / halo2 `Params::g`
+ *                                   (read by the reference at lib/src/utils.rs:104-110)
+ *
+ * INTEGRATION.md shows the Rust-side stubs.  Conventions:
+ *   - plain pointers and sizes, little-endian u64 limbs (== little-endian u32 words);
+ *   - field elements in Montgomery form, R = 2^256 (2^384 for BLS12-381 Fq), unless stated;
+ *   - affine points are (x, y); the point at infinity is encoded as x = y = 0;
+ *   - results are Jacobian (X, Y, Z), identity has Z = 0 -- the in-memory form of ark-ec 0.3
+ *     `GroupProjective` and pasta_curves 0.4 `Ep`/`Eq`;
+ *   - every function returns 0 on success or a negative zk_status; nothing throws or aborts;
+ *   - thread-safe: calls are serialised per process on an internal mutex; one process drives
+ *     one GPU (multi-GPU = one process per GPU, see zk_msm_opts.window_begin/window_end);
+ *   - "device" pointers must be 16-byte aligned HBM addresses of the current device.
+ *   - There is no CPU fallback: without a usable MI355X every compute entry point fails with
+ *     ZK_ERR_NO_DEVICE.
+ */
+#ifndef ZKCP_AMD_H
+#define ZKCP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ZK_PALLAS = 0,       /* y^2 = x^3 + 5 over Fp, scalars in Fq   (pasta_curves 0.4 `pallas`) */
+    ZK_VESTA = 1,        /* y^2 = x^3 + 5 over Fq, scalars in Fp   (pasta_curves 0.4 `vesta`; halo2 commitments over pallas::Base) */
+    ZK_BN254_G1 = 2,     /* ark-bn254 0.3 G1 */
+    ZK_BLS12_381_G1 = 3  /* ark-bls12-381 0.3 G1 -- the curve the reference proves on (lib/src/lib.rs:21-24) */
+} zk_curve_t;
+
+typedef enum {
+    ZK_FP_PALLAS = 0,    /* pasta Fp  (Pallas base = Vesta scalar) */
+    ZK_FQ_PALLAS = 1,    /* pasta Fq  (Pallas scalar = Vesta base) */
+    ZK_FR_BN254 = 2,
+    ZK_FR_BLS12_381 = 3
+} zk_field_t;
+
+typedef enum {
+    ZK_OK = 0,
+    ZK_ERR_INVALID_ARG = -1,
+    ZK_ERR_NOT_INITIALIZED = -2,
+    ZK_ERR_NO_DEVICE = -3,
+    ZK_ERR_HIP = -4,
+    ZK_ERR_OOM = -5,
+    ZK_ERR_UNSUPPORTED = -6,
+    ZK_ERR_BAD_HANDLE = -7
+} zk_status;
+
+/* MSM tuning / sharding.  Zero-initialise for defaults. */
+typedef struct {
+    int window_bits;    /* c; 0 = choose from n */
+    int window_begin;   /* this call sums windows [window_begin, window_end) of the signed-digit      */
+    int window_end;     /*   decomposition, already weighted by 2^(c*w); 0,0 = all windows (one GPU) */
+    int reserved;
+} zk_msm_opts;
+
+/* Wall-clock of the phases of the last zk_msm* call on this process (milliseconds, HIP events). */
+typedef struct {
+    float digits_hist_ms, scan_ms, scatter_ms, accumulate_ms, reduce_ms, host_tail_ms, total_ms;
+    int window_bits, windows_total, windows_done;
+} zk_msm_profile;
+
+/* ---- lifecycle ---- */
+int zk_init(int device_id);            /* binds this process to one GPU; idempotent for the same id */
+int zk_shutdown(void);                 /* frees every device allocation made by the library */
+const char *zk_strerror(int status);
+int zk_backend_info(char *buf, uint64_t buflen); /* e.g. "hip gfx950 AMD Instinct MI355X cu=256" */
+
+/* ---- sizes ---- */
+int zk_field_limbs64(zk_field_t f);            /* u64 limbs per scalar-field element (4) */
+int zk_curve_base_limbs64(zk_curve_t c);       /* u64 limbs per base-field element (4, or 6 for BLS12-381) */
+int zk_curve_scalar_field(zk_curve_t c);       /* zk_field_t of the curve's scalars */
+int zk_msm_window_bits(zk_curve_t c, uint64_t n, int requested);            /* c actually used */
+int zk_msm_window_count(zk_curve_t c, uint64_t n, int window_bits);         /* ceil((bits+1)/c) */
+
+/* ---- SRS residency: bases are fixed per circuit; upload once, reuse for every proof ---- */
+int zk_bases_upload(zk_curve_t c, const void *affine_xy_mont_host, uint64_t n, uint64_t *handle_out);
+int zk_bases_adopt_device(zk_curve_t c, const void *affine_xy_mont_dev, uint64_t n, uint64_t *handle_out); /* no copy; caller keeps it alive */
+int zk_bases_free(uint64_t handle);
+
+/* ---- MSM: out = sum_i scalars[i] * bases[i], i < n <= bases length ----
+ * scalars: n x 4 u64.  scalars_are_montgomery = 0 for ark-ec (canonical BigInt from into_repr()),
+ * 1 for halo2 (Fp/Fq as stored).  out: Jacobian (X, Y, Z), 3 x base limbs, host memory. */
+int zk_msm(zk_curve_t c, uint64_t bases_handle, const void *scalars_host, uint64_t n,
+           int scalars_are_montgomery, const zk_msm_opts *opts, void *out_jacobian_host);
+int zk_msm_device(zk_curve_t c, uint64_t bases_handle, const void *scalars_dev, uint64_t n,
+                  int scalars_are_montgomery, const zk_msm_opts *opts, void *out_jacobian_host,
+                  void *hip_stream);
+int zk_msm_last_profile(zk_msm_profile *out);
+
+/* ---- NTT: in-place radix-2 DFT of size 2^log_n, natural order in and out ----
+ * a[k] <- sum_j a[j] * omega^(jk); the caller passes omega (halo2 best_fft semantics: omega or
+ * omega^-1, no implicit scaling).  scale_by_n_inv = 1 additionally multiplies by (2^log_n)^-1
+ * (ark-poly ifft_in_place semantics when omega = group_gen_inv). */
+int zk_ntt(zk_field_t f, void *a_mont_host, uint32_t log_n, const void *omega_mont_host, int scale_by_n_inv);
+int zk_ntt_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *omega_mont_host,
+                  int scale_by_n_inv, void *hip_stream);
+
+/* a[i] *= g^i, i < 2^log_n */
+int zk_coset_mul(zk_field_t f, void *a_mont_host, uint32_t log_n, const void *g_mont_host);
+int zk_coset_mul_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *g_mont_host, void *hip_stream);
+
+/* ---- host-side helpers a shim needs around the two kernels ---- */
+int zk_field_root_of_unity(zk_field_t f, uint32_t log_n, void *omega_mont_out);   /* ark group_gen / halo2 omega for size 2^log_n */
+int zk_field_multiplicative_generator(zk_field_t f, void *g_mont_out);            /* ark coset shift (7 BLS12-381 Fr, 5 BN254 Fr, 5 pasta) */
+int zk_field_inverse(zk_field_t f, const void *a_mont, void *out_mont);
+int zk_point_add(zk_curve_t c, const void *jac_a, const void *jac_b, void *jac_out);  /* combine per-GPU partial sums */
+int zk_point_to_affine(zk_curve_t c, const void *jac, void *affine_out);               /* identity -> (0, 0) */
+
+/* out[i] = [k_i] G (affine, Montgomery) for canonical scalars k_i; device buffers.
+ * Seeded synthetic SRS for tests/benches and the kernel under fixed-base setup work. */
+int zk_fixed_base_mul_device(zk_curve_t c, const void *scalars_canonical_dev, uint64_t n, void *affine_out_dev,
+                             void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKCP_AMD_H */

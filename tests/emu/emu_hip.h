@@ -1,0 +1,97 @@
+// TEST INFRASTRUCTURE -- a minimal HIP-semantics emulator so that `pytest -m "not gpu"` (no GPU
+// in the build container) and CPU sanitizers can execute the kernel sources of
+// contangle-zkcp_amd/csrc unchanged: each workgroup runs as a set of cooperative fibers
+// (ucontext), `__syncthreads()` is a fiber barrier, `__shared__` is static storage, atomics are
+// plain read-modify-writes (fibers never run concurrently).
+//
+// It is NOT a backend: nothing in the product loads tests/emu/libzkcp_emu.so, bench.py and
+// __graft_entry__.smoke() never touch it, and the product library fails with ZK_ERR_NO_DEVICE
+// when no MI355X is present.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+
+namespace emu {
+struct Dim3 {
+    unsigned x, y, z;
+};
+struct ThreadCtx {
+    Dim3 tid, bid;
+};
+extern ThreadCtx* cur;
+extern Dim3 g_block_dim, g_grid_dim;
+extern char* g_dyn_smem;
+void launch(unsigned grid, unsigned block, size_t shmem, const std::function<void()>& body);
+void syncthreads();
+}  // namespace emu
+
+#define threadIdx (emu::cur->tid)
+#define blockIdx (emu::cur->bid)
+#define blockDim (emu::g_block_dim)
+#define gridDim (emu::g_grid_dim)
+#define __syncthreads() emu::syncthreads()
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+#define ZK_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(emu::g_dyn_smem)
+#define ZK_EMU_STRIP_PARENS(...) __VA_ARGS__
+#define ZK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    emu::launch((unsigned)(grid), (unsigned)(block), (size_t)(shmem), [&]() { (ZK_EMU_STRIP_PARENS kernel)(__VA_ARGS__); })
+
+template <class T>
+static inline T atomicAdd(T* p, T v) {
+    T o = *p;
+    *p = o + v;
+    return o;
+}
+static inline uint32_t __brev(uint32_t x) {
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+    return __builtin_bswap32(x);
+}
+static inline int __clz(uint32_t x) { return x ? __builtin_clz(x) : 32; }
+static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
+
+// ---- host runtime shims (device memory == host memory) ----
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef struct emuEvent* hipEvent_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+struct hipDeviceProp_t {
+    char name[256];
+    char gcnArchName[256];
+    int multiProcessorCount;
+};
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
+hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipFree(void* p);
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
+hipError_t hipStreamSynchronize(hipStream_t st);
+hipError_t hipDeviceSynchronize();
+hipError_t hipGetLastError();
+const char* hipGetErrorString(hipError_t e);
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t st);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+#define hipFuncAttributeMaxDynamicSharedMemorySize 0
+template <class K>
+static inline hipError_t hipFuncSetAttribute(K, int, int) {
+    return hipSuccess;
+}

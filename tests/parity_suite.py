@@ -1,0 +1,210 @@
+"""Parity cases shared by the two tiers:
+  * tests/test_gpu_parity.py  (-m gpu)      : the HIP library on a real MI355X, through the C ABI
+  * tests/test_emu_parity.py  (-m "not gpu"): the same sources under tests/emu (kernel-logic check on CPU)
+Every case compares against the CPU oracle (oracle/) and/or the pure-Python golden fixtures.
+Bar: bit-exact (integer arithmetic) after normalising points to affine."""
+import json
+import os
+
+import numpy as np
+
+from oracle import pyref
+from oracle import zk_oracle as orc
+
+H = lambda s: int(s, 16)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NTT_FIELDS = ["PallasFp", "PallasFq", "Bn254Fr", "Bls381Fr"]
+CURVES = ["Pallas", "Vesta", "Bn254G1", "Bls381G1"]
+
+
+def rand_field(name, n, seed):
+    """n uniform elements of the field, Montgomery form, uint64 [n,4] (vectorised splitmix64 + rejection)."""
+    p = pyref.FIELDS[name][0]
+    out = np.zeros((n, 4), dtype=np.uint64)
+    todo = np.arange(n)
+    ctr = np.uint64(seed)
+    top_mask = np.uint64((1 << (p.bit_length() - 192)) - 1)
+    pl = [np.uint64((p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) for i in range(4)]
+    rnd = 0
+    while todo.size:
+        m = todo.size
+        with np.errstate(over="ignore"):
+            idx = (np.arange(m * 4, dtype=np.uint64) + np.uint64(rnd * 0x1000003) * np.uint64(n * 4 + 1)
+                   + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15))
+            z = idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x632BE59BD9B4E019)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        c = z.reshape(m, 4).copy()
+        c[:, 3] &= top_mask
+        lt = np.zeros(m, dtype=bool)
+        eq = np.ones(m, dtype=bool)
+        for i in (3, 2, 1, 0):
+            lt |= eq & (c[:, i] < pl[i])
+            eq &= c[:, i] == pl[i]
+        out[todo[lt]] = c[lt]
+        todo = todo[~lt]
+        rnd += 1
+    return out
+
+
+def scalars_for(curve, n, seed, realistic=False):
+    """canonical scalars [n,4] in [0, r); `realistic` = 40% zeros, 25% ones, 10% < 2^8."""
+    sf = pyref.CURVES[curve][1]
+    s = rand_field(sf, n, seed)   # uniform in [0, r): read as canonical integers
+    if realistic:
+        u = rand_field(sf, n, seed + 1)[:, 0] % np.uint64(100)
+        z, o, sm = u < 40, (u >= 40) & (u < 65), (u >= 65) & (u < 75)
+        s[z] = 0
+        s[o] = 0
+        s[o, 0] = 1
+        s[sm, 1:] = 0
+        s[sm, 0] &= np.uint64(0xFF)
+    return s
+
+
+_bases_cache = {}
+
+
+def bases_for(curve, n, seed=11):
+    """P_i = [k_i]G from the oracle (cached per process)."""
+    key = (curve, n, seed)
+    if key not in _bases_cache:
+        ks = scalars_for(curve, n, seed + 1000)
+        _bases_cache[key] = orc.fixed_base_mul(curve, ks, threads=8)
+    return _bases_cache[key]
+
+
+# ------------------------------------------------------------------ NTT
+def check_ntt_golden(zk):
+    v = json.load(open(os.path.join(GOLD, "ntt_vectors.json")))["fields"]
+    for name in NTT_FIELDS:
+        g = orc.field_generator(name)
+        assert (zk.multiplicative_generator(name) == g).all()
+        for case in v[name]["cases"]:
+            logn = case["logn"]
+            a = orc.to_mont(name, orc.ints_to_array([H(x) for x in case["in"]], 4))
+            want = lambda k: orc.to_mont(name, orc.ints_to_array([H(x) for x in case[k]], 4))
+            w = zk.root_of_unity(name, logn)
+            assert (w == orc.root_of_unity(name, logn)).all()
+            assert (zk.halo2.best_fft(name, a, w, logn) == want("fft")).all(), (name, logn)
+            dom = zk.ark.Radix2EvaluationDomain(name, 1 << logn)
+            assert dom.size == 1 << logn
+            assert (dom.fft_in_place(a) == want("fft")).all()
+            assert (dom.ifft_in_place(a) == want("ifft")).all(), (name, logn)
+            assert (dom.coset_fft_in_place(a) == want("coset_fft")).all()
+            assert (dom.coset_ifft_in_place(a) == want("coset_ifft")).all()
+
+
+def check_ntt_vs_oracle(zk, name, logn, seed=3, threads=8):
+    a = rand_field(name, 1 << logn, seed)
+    w = orc.root_of_unity(name, logn)
+    got = zk.halo2.best_fft(name, a, w, logn)
+    assert (got == orc.halo2_best_fft(name, a, w, logn, threads=threads)).all(), (name, logn, "best_fft")
+    dom = zk.ark.Radix2EvaluationDomain(name, 1 << logn)
+    assert (dom.ifft_in_place(got) == a).all(), (name, logn, "ifft(fft(x)) != x")
+    if logn <= 14:
+        for kind in ("ifft", "coset_fft", "coset_ifft"):
+            r = getattr(dom, kind + "_in_place")(a)
+            assert (r == orc.ark_fft(name, a, kind, threads=threads)).all(), (name, logn, kind)
+
+
+# ------------------------------------------------------------------ MSM
+def affine_of(zk, curve, jac):
+    return zk.point_to_affine(curve, jac)
+
+
+def check_msm_golden(zk):
+    v = json.load(open(os.path.join(GOLD, "msm_vectors.json")))["curves"]
+    for cname in CURVES:
+        bf, sf = pyref.CURVES[cname][0], pyref.CURVES[cname][1]
+        nl = pyref.FIELDS[bf][2]
+        for case in v[cname]["cases"]:
+            n = case["n"]
+            pts = np.zeros((n, 2 * nl), dtype=np.uint64)
+            for i, P in enumerate(case["points"]):
+                if P is not None:
+                    pts[i, :nl] = orc.int_to_limbs(pyref.mont(bf, H(P[0])), nl)
+                    pts[i, nl:] = orc.int_to_limbs(pyref.mont(bf, H(P[1])), nl)
+            sc = orc.ints_to_array([H(s) for s in case["scalars"]], 4)
+            exp = np.zeros(2 * nl, dtype=np.uint64)
+            if case["result"] is not None:
+                exp[:nl] = orc.int_to_limbs(pyref.mont(bf, H(case["result"][0])), nl)
+                exp[nl:] = orc.int_to_limbs(pyref.mont(bf, H(case["result"][1])), nl)
+            bases = zk.Bases(cname, pts)
+            for wb in (0, 3, 7):
+                got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=wb))
+                assert (got == exp).all(), (cname, n, wb)
+            got = affine_of(zk, cname, zk.ark.VariableBaseMSM.multi_scalar_mul(bases, sc))
+            assert (got == exp).all()
+            got = affine_of(zk, cname, zk.halo2.best_multiexp(orc.to_mont(sf, sc), bases))
+            assert (got == exp).all(), (cname, n, "halo2")
+            bases.free()
+
+
+def check_msm_vs_oracle(zk, cname, n, window_bits=0, realistic=False, seed=5, threads=8):
+    sf = pyref.CURVES[cname][1]
+    pts = bases_for(cname, n)
+    sc = scalars_for(cname, n, seed, realistic)
+    exp = orc.msm_ark(cname, pts, sc, threads=threads)
+    bases = zk.Bases(cname, pts)
+    got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
+    assert (got == exp).all(), (cname, n, window_bits, realistic)
+    assert orc.on_curve(cname, got)
+    # halo2 entry: Montgomery scalars
+    got = affine_of(zk, cname, zk.halo2.best_multiexp(orc.to_mont(sf, sc), bases))
+    assert (got == exp).all(), (cname, n, "montgomery scalars")
+    bases.free()
+    return exp
+
+
+def check_msm_window_sharding(zk, cname, n, window_bits, parts):
+    """window-range partial sums (one per 'GPU') added up = the full MSM."""
+    pts = bases_for(cname, n)
+    sc = scalars_for(cname, n, 9)
+    bases = zk.Bases(cname, pts)
+    full = zk.msm(bases, sc, window_bits=window_bits)
+    W = zk.msm_window_count(cname, n, window_bits)
+    acc = None
+    for g in range(parts):
+        lo, hi = W * g // parts, W * (g + 1) // parts
+        if lo == hi:
+            continue
+        part = zk.msm(bases, sc, window_bits=window_bits, windows=(lo, hi))
+        acc = part if acc is None else zk.point_add(cname, acc, part)
+    assert (affine_of(zk, cname, acc) == affine_of(zk, cname, full)).all()
+    assert (affine_of(zk, cname, full) == orc.msm_ark(cname, pts, sc, threads=8)).all()
+    bases.free()
+
+
+def check_msm_edges(zk, cname):
+    nl = pyref.FIELDS[pyref.CURVES[cname][0]][2]
+    g = orc.curve_generator(cname)
+    r = pyref.FIELDS[pyref.CURVES[cname][1]][0]
+    # empty input -> identity (Z = 0)
+    bases = zk.Bases(cname, np.zeros((0, 2 * nl), dtype=np.uint64))
+    out = zk.msm(bases, np.zeros((0, 4), dtype=np.uint64))
+    assert not out[2 * nl:].any() and not affine_of(zk, cname, out).any()
+    bases.free()
+    # all-zero scalars, all-identity bases
+    n = 40
+    bases = zk.Bases(cname, np.tile(g, (n, 1)))
+    assert not affine_of(zk, cname, zk.msm(bases, np.zeros((n, 4), dtype=np.uint64))).any()
+    # every point equal (forces the doubling branch of the mixed add), scalars 1..n
+    sc = np.zeros((n, 4), dtype=np.uint64)
+    sc[:, 0] = np.arange(1, n + 1, dtype=np.uint64)
+    exp = orc.scalar_mul(cname, g, orc.int_to_limbs(n * (n + 1) // 2, 4))
+    assert (affine_of(zk, cname, zk.msm(bases, sc, window_bits=4)) == exp).all()
+    # maximal scalars r-1 on all: sum = -n G
+    sc = np.tile(orc.int_to_limbs(r - 1, 4), (n, 1))
+    exp = orc.scalar_mul(cname, g, orc.int_to_limbs((r - n) % r, 4))
+    for wb in (0, 5, 13):
+        assert (affine_of(zk, cname, zk.msm(bases, sc, window_bits=wb)) == exp).all(), wb
+    # ragged: fewer scalars than bases uses the common prefix (ark: min(len, len))
+    out = zk.ark.VariableBaseMSM.multi_scalar_mul(bases, sc[:7])
+    assert (affine_of(zk, cname, out) == orc.scalar_mul(cname, g, orc.int_to_limbs((7 * (r - 1)) % r, 4))).all()
+    bases.free()
+    # identity bases only
+    bases = zk.Bases(cname, np.zeros((n, 2 * nl), dtype=np.uint64))
+    assert not affine_of(zk, cname, zk.msm(bases, sc)).any()
+    bases.free()

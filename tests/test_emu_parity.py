@@ -1,0 +1,67 @@
+"""CPU tier: kernel-logic parity.  The HIP sources of contangle-zkcp_amd/csrc are compiled with
+g++ against tests/emu (a HIP-semantics emulator, TEST INFRASTRUCTURE) and driven through the
+same C ABI and Python mirror as on the GPU; results are compared with the oracle and the
+pure-Python fixtures.  The real parity gate is tests/test_gpu_parity.py (-m gpu)."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import parity_suite as ps  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def zk():
+    spec = importlib.util.spec_from_file_location("zk_build", os.path.join(ROOT, "contangle-zkcp_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    emu = b.build_emu()
+    import contangle_zkcp_amd as zk
+    zk.load(path=emu)
+    zk.init(0)
+    assert zk.backend_info().startswith("emu")
+    yield zk
+    zk.shutdown()
+    zk._lib = None
+
+
+def test_ntt_golden(zk):
+    ps.check_ntt_golden(zk)
+
+
+@pytest.mark.parametrize("max_logr,logt", [("10", "2"), ("3", "1"), ("2", "2"), ("4", "0")])
+def test_ntt_multipass(zk, monkeypatch, max_logr, logt):
+    # small radices force 2-, 3- and 4-pass plans at sizes the emulator handles quickly
+    monkeypatch.setenv("ZK_NTT_MAX_LOGR", max_logr)
+    monkeypatch.setenv("ZK_NTT_LOGT", logt)
+    for name, logn in (("PallasFp", 7), ("Bls381Fr", 8), ("PallasFq", 5), ("Bn254Fr", 6), ("PallasFp", 1), ("PallasFp", 2)):
+        if (logn + int(max_logr) - 1) // int(max_logr) > 4:
+            continue
+        ps.check_ntt_vs_oracle(zk, name, logn)
+
+
+def test_ntt_two_pass_default_plan(zk):
+    ps.check_ntt_vs_oracle(zk, "PallasFp", 12)
+
+
+def test_msm_golden(zk):
+    ps.check_msm_golden(zk)
+
+
+@pytest.mark.parametrize("cname", ps.CURVES)
+def test_msm_edges(zk, cname):
+    ps.check_msm_edges(zk, cname)
+
+
+@pytest.mark.parametrize("cname,n,wb,realistic", [
+    ("Pallas", 300, 0, False), ("Vesta", 257, 6, True), ("Bn254G1", 200, 5, False), ("Bls381G1", 150, 7, True),
+    ("Pallas", 1024, 8, True)])
+def test_msm_vs_oracle(zk, cname, n, wb, realistic):
+    ps.check_msm_vs_oracle(zk, cname, n, wb, realistic)
+
+
+def test_msm_window_sharding(zk):
+    ps.check_msm_window_sharding(zk, "Vesta", 128, 6, 4)
+    ps.check_msm_window_sharding(zk, "Bls381G1", 64, 5, 8)
