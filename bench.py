@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline bench: BASELINE.json configs[1] -- one 2^20-point MSM + one 2^20 NTT per step, inputs
+resident in HBM, through the C ABI (libzkcp_amd.so).
+
+  step      = commit one 2^20-row column, halo2-style: NTT over Fp (pasta) + Vesta MSM with Fp scalars
+              (an Fp NTT pairs with a Vesta MSM; `--curve Pallas` runs the Fq/Pallas twin)
+  metric    = constraints/sec = rows processed / wall-clock of the timed region (whole job)
+  N > 1     = the MSM is window-range sharded over the N ranks (one process per GPU) and combined
+              with one all_gather of a Jacobian point over RCCL (contangle-zkcp_amd/dist.py); the NTT
+              stays single-GPU and is taken by rank (step mod N).  Total work per step is fixed
+              -> "scaling": "strong".
+
+Launch: `python bench.py [--gpus 1 --steps K --warmup W]`, or for N > 1
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--logn", type=int, default=20)
+    ap.add_argument("--curve", default="Vesta", choices=["Vesta", "Pallas", "Bn254G1", "Bls381G1"])
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--realistic", action="store_true", help="0/1-heavy witness mix (SURVEY 8d)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import contangle_zkcp_amd as zk
+    from contangle_zkcp_amd import dist as zkdist
+    import parity_suite as ps
+    from oracle import pyref
+
+    zk.load()
+    zk.init(local_rank)
+    curve = args.curve
+    sfield = pyref.CURVES[curve][1]               # scalar field of the MSM == field of the NTT
+    n = 1 << args.logn
+    nl = zk.base_limbs(curve)
+    st = torch.cuda.current_stream().cuda_stream
+
+    # ---- synthetic inputs, generated once and left resident in HBM (same seeds on every rank)
+    ks = ps.scalars_for(curve, n, 0x5EED)
+    d_pts = torch.empty((n, 2 * nl), dtype=torch.int64, device="cuda")
+    zk.fixed_base_mul_device(curve, torch.from_numpy(ks.view(np.int64)).cuda(), d_pts, n, stream=st)   # P_i = [k_i]G
+    torch.cuda.synchronize()
+    bases = zk.Bases(curve, device_tensor=d_pts, n=n)
+    sc_host = ps.scalars_for(curve, n, 0xC0DE, realistic=args.realistic)
+    d_sc = torch.from_numpy(sc_host.view(np.int64)).cuda()             # canonical scalars (ark BigInt form)
+    a_host = ps.rand_field(sfield, n, 0xF00D)
+    d_a = torch.from_numpy(a_host.view(np.int64)).cuda()
+    omega = zk.root_of_unity(sfield, args.logn)
+
+    prof_acc = {"accumulate_ms": 0.0, "total_ms": 0.0, "reduce_ms": 0.0, "digits_hist_ms": 0.0, "scatter_ms": 0.0,
+                "scan_ms": 0.0, "host_tail_ms": 0.0}
+    ntt_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    result = {}
+
+    def step(i, timed):
+        if i % world == rank:
+            if timed:
+                ntt_ev[i][0].record()
+            zk.ntt(sfield, d_a, omega, stream=st)
+            if timed:
+                ntt_ev[i][1].record()
+        out = zkdist.msm_sharded(bases, d_sc, window_bits=args.window_bits, stream=st)
+        if timed:
+            p = zk.msm_last_profile()
+            for k in prof_acc:
+                prof_acc[k] += p[k]
+            result["profile"] = p
+        result["msm"] = out
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = n * args.steps / elapsed
+        msm_ms = prof_acc["total_ms"] / args.steps
+        acc_ms = prof_acc["accumulate_ms"] / args.steps
+        ntt_ms = [a.elapsed_time(b) for i, (a, b) in enumerate(ntt_ev) if i % world == rank]
+        ntt_ms = sum(ntt_ms) / max(1, len(ntt_ms))
+        prof = result["profile"]
+        # roofline of the dominant kernel (msm_accumulate_kernel): algorithmic bytes = every scalar and every
+        # affine base read once = n * (32 + 2*limbs*8) B per launch (SURVEY 8d / BASELINE.md section 4);
+        # at N ranks one launch covers windows_done/windows_total of the windows -> the same share of the bytes.
+        alg_bytes = n * (32 + 2 * nl * 8) * prof["windows_done"] / prof["windows_total"]
+        achieved = alg_bytes / (acc_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("msm_accumulate_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "constraints/sec", "value": value, "unit": "constraints/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32x8 (256-bit Montgomery integers)" if nl == 4 else "u32x12 (384-bit Montgomery integers)",
+            "data": "synthetic",
+            "config": {"workload": "2^%d-point %s MSM + 2^%d %s NTT per step (BASELINE configs[1])" % (args.logn, curve, args.logn, sfield),
+                       "rows_per_step": n, "scalars": "realistic-0/1-mix" if args.realistic else "uniform",
+                       "parallelism": "msm-window-shard x%d + all_gather" % world if world > 1 else "single-gpu",
+                       "window_bits": prof["window_bits"], "windows": prof["windows_total"]},
+            "msm_mops": n / (msm_ms * 1e-3) / 1e6 * (prof["windows_total"] / prof["windows_done"]) if world == 1 else n / (ms_per_step * 1e-3) / 1e6,
+            "msm_ms": msm_ms, "ntt_ms": ntt_ms,
+            "msm_phases_ms": {k: prof_acc[k] / args.steps for k in prof_acc},
+            "roofline": {"kernel": "msm_accumulate_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "note": "integer-ALU-bound by construction (SURVEY 8d); see int_mad_roofline"},
+        }
+        # second roofline: 32x32->64 MADs actually needed vs the measured v_mad_u64_u32 peak (tools/microbench)
+        mads_per_mul = {"PallasFp": 88, "PallasFq": 88}.get(pyref.CURVES[curve][0], 2 * (2 * nl) ** 2)
+        adds = n * prof["windows_done"]
+        line["int_mad_roofline"] = {"achieved_tmad_s": adds * 10 * mads_per_mul / (acc_ms * 1e-3) / 1e12, "peak_tmad_s": 33.7,
+                                    "note": "mixed adds x 10 field mul x MADs/mul over accumulate time; peak = measured v_mad_u64_u32 rate"}
+        line["int_mad_roofline"]["frac"] = line["int_mad_roofline"]["achieved_tmad_s"] / 33.7
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(curve, sfield, args.logn, d_pts, sc_host, a_host, omega, result["msm"], zk)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(curve, sfield, logn, d_pts, sc_host, a_host, omega, gpu_msm, zk):
+    """The oracle (CPU restatement of ark-ec 0.3 Pippenger + halo2 0.2 best_fft, 'port') timed on this box's host
+    cores on the same inputs; also a final bit-exact check of the GPU result.  Bounded: one full-size repetition."""
+    import numpy as np
+    from oracle import zk_oracle as orc
+    cores = os.cpu_count() or 1
+    n = 1 << logn
+    pts = d_pts.cpu().numpy().view(np.uint64)
+    t0 = time.perf_counter()
+    exp = orc.msm_ark(curve, pts, sc_host, threads=cores)
+    t_msm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.halo2_best_fft(sfield, a_host, omega, logn, threads=cores)
+    t_ntt = time.perf_counter() - t0
+    ok = bool((zk.point_to_affine(curve, gpu_msm) == exp).all())
+    return {"value": n / (t_msm + t_ntt), "unit": "constraints/s", "cores": cores, "kind": "port",
+            "sample": "1 full step: 2^%d MSM (ark-ec 0.3 Pippenger restatement, %.2f s) + 2^%d NTT (halo2 best_fft restatement, %.2f s)"
+                      % (logn, t_msm, logn, t_ntt),
+            "msm_mops": n / t_msm / 1e6, "gpu_result_matches": ok}
+
+
+if __name__ == "__main__":
+    main()

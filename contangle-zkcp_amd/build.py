@@ -1,5 +1,7 @@
 """Build the HIP extension (libzkcp_amd.so) for gfx950 in-tree, plus -- for the CPU test tier
-only -- the emulator build under tests/emu/.  hipcc cross-compiles without a GPU."""
+only -- the emulator build under tests/emu/.  hipcc cross-compiles without a GPU.  One
+translation unit per curve / field, compiled in parallel."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -12,8 +14,18 @@ LIB = os.path.join(PKG, "libzkcp_amd.so")
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libzkcp_emu.so")
 
-SOURCES = ["zk_api.cc"]
-HEADERS = ["zk_params.h", "zk_field.h", "zk_curve.h", "zk_kernels.h", "zk_rt.h"]
+CURVES = ["Pallas", "Vesta", "Bn254G1", "Bls381G1"]
+FIELDS = ["PallasFp", "PallasFq", "Bn254Fr", "Bls381Fr"]
+# (source, extra define, object tag)
+UNITS = [("zk_api.cc", None, "api")] + \
+        [("zk_msm_inst.cc", "ZK_CURVE=" + c, "msm_" + c) for c in CURVES] + \
+        [("zk_ntt_inst.cc", "ZK_FIELD=" + f, "ntt_" + f) for f in FIELDS]
+HEADERS = ["zk_params.h", "zk_field.h", "zk_curve.h", "zk_kernels.h", "zk_rt.h", "zk_internal.h", "zk_msm.inl", "zk_ntt.inl"]
+
+
+def _deps():
+    files = [os.path.join(CSRC, f) for f in HEADERS + sorted({u[0] for u in UNITS})]
+    return files + [os.path.join(ROOT, "include", "zkcp_amd.h")]
 
 
 def _newer(target, deps):
@@ -23,10 +35,6 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _deps():
-    return [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "zkcp_amd.h")]
-
-
 def hipcc_path():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -34,35 +42,64 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
-def build_hip(force=False, verbose=False):
-    if not force and not _newer(LIB, _deps()):
-        return LIB
-    cmd = [hipcc_path(), "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB + ".tmp"]
+def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def _compile_all(base_cmd, objdir, deps, verbose, jobs):
+    os.makedirs(objdir, exist_ok=True)
+    objs, todo = [], []
+    for src, define, tag in UNITS:
+        obj = os.path.join(objdir, tag + ".o")
+        objs.append(obj)
+        if _newer(obj, deps):
+            cmd = base_cmd + (["-D" + define] if define else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+            todo.append(cmd)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(lambda c: _run(c, verbose), todo))
+    return objs
+
+
+def build_hip(force=False, verbose=False, jobs=None):
+    deps = _deps()
+    if not force and not _newer(LIB, deps):
+        return LIB
+    jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
+    objdir = os.path.join(PKG, "build", "hip")
+    if force:
+        shutil.rmtree(objdir, ignore_errors=True)
+    base = [hipcc_path(), "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+            "-fno-gpu-rdc", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    objs = _compile_all(base, objdir, deps, verbose, jobs)
+    _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB + ".tmp"] + objs, verbose)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
-def build_emu(force=False, verbose=False, sanitize=False):
+def build_emu(force=False, verbose=False, sanitize=False, jobs=None):
     """TEST INFRASTRUCTURE: the same sources against tests/emu/emu_hip.h (g++)."""
     out = EMU_LIB if not sanitize else EMU_LIB.replace(".so", "_ubsan.so")
     deps = _deps() + [os.path.join(EMU_DIR, "emu_hip.h"), os.path.join(EMU_DIR, "emu_hip.cpp")]
     if not force and not _newer(out, deps):
         return out
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DZK_EMU", "-fvisibility=hidden",
-           "-I" + EMU_DIR, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
+    objdir = os.path.join(PKG, "build", "emu_ubsan" if sanitize else "emu")
+    if force:
+        shutil.rmtree(objdir, ignore_errors=True)
+    base = ["g++", "-O2", "-std=c++17", "-fPIC", "-DZK_EMU", "-fvisibility=hidden", "-I" + EMU_DIR,
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if sanitize:
-        cmd += ["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-g"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(EMU_DIR, "emu_hip.cpp"), "-o", out + ".tmp"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        base += ["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-g"]
+    objs = _compile_all(base, objdir, deps, verbose, jobs)
+    link = ["g++", "-shared", "-fPIC"] + (["-fsanitize=undefined"] if sanitize else []) + \
+           ["-I" + EMU_DIR, "-O2", "-std=c++17", os.path.join(EMU_DIR, "emu_hip.cpp")] + objs + ["-o", out + ".tmp"]
+    _run(link, verbose)
     os.replace(out + ".tmp", out)
     return out
 

@@ -90,7 +90,7 @@ __device__ __forceinline__ void tw_get(Fe<F>& w, const Fe<F>* __restrict__ tw, u
 }
 
 template <class F>
-__global__ void ntt_pass_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out, const Fe<F>* __restrict__ tw,
+__global__ void __launch_bounds__(256) ntt_pass_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out, const Fe<F>* __restrict__ tw,
                                 NttPass A, Fe<F> scale) {
     ZK_DYN_SHARED(uint32_t, lds);
     constexpr int NL = F::N;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void for_each_digit(const uint32_t (&s)[Fr::N], const
 }
 
 template <class C>
-__global__ void msm_hist_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh, uint32_t* __restrict__ counts) {
+__global__ void __launch_bounds__(256) msm_hist_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh, uint32_t* __restrict__ counts) {
     using Fr = typename C::Fr;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sh.n) return;
@@ -275,8 +275,10 @@ __global__ void msm_hist_kernel(const Fe<typename C::Fr>* __restrict__ scalars, 
     for_each_digit<Fr>(s, sh, [&](int w, uint32_t b, bool) { atomicAdd(&counts[(uint32_t)w * sh.nbk + b], 1u); });
 }
 
-// offs[i] = sum_{k<i} counts[k]; single workgroup of 1024 lanes
-__global__ void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t m) {
+// offs[i] = sum_{k<i} counts[k]; single workgroup of 1024 lanes (template only so the header can be
+// included from several translation units)
+template <class Tag>
+__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t m) {
     __shared__ uint32_t part[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (m + 1023) / 1024;
@@ -300,7 +302,7 @@ __global__ void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* _
 }
 
 template <class C>
-__global__ void msm_scatter_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ offs,
+__global__ void __launch_bounds__(256) msm_scatter_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ offs,
                                    uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
     using Fr = typename C::Fr;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -315,7 +317,7 @@ __global__ void msm_scatter_kernel(const Fe<typename C::Fr>* __restrict__ scalar
 }
 
 template <class C>
-__global__ void msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                       const uint32_t* __restrict__ offs, const uint32_t* __restrict__ counts,
                                       XYZZ<C>* __restrict__ buckets, uint32_t nbuckets) {
     const uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,7 +337,7 @@ __global__ void msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const
 // slice t of window w covers bucket indices [t*L, (t+1)*L) (weights index+1):
 //   X_t = sum_l (l+1) B_{tL+l} + [t*L] * sum_l B_{tL+l}
 template <class C>
-__global__ void msm_reduce_kernel(const XYZZ<C>* __restrict__ buckets, XYZZ<C>* __restrict__ out, uint32_t nbk, uint32_t L,
+__global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restrict__ buckets, XYZZ<C>* __restrict__ out, uint32_t nbk, uint32_t L,
                                   uint32_t slices_per_window, uint32_t nslices) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     if (gt >= nslices) return;
@@ -367,7 +369,7 @@ __global__ void msm_reduce_kernel(const XYZZ<C>* __restrict__ buckets, XYZZ<C>* 
 
 // out[s*per_out + o] = sum of in[s*per_in + o*chunk .. +chunk), chunk = 256*E; one workgroup (256 lanes) per output
 template <class C>
-__global__ void msm_sum_kernel(const XYZZ<C>* __restrict__ in, XYZZ<C>* __restrict__ out, uint32_t per_in, uint32_t per_out,
+__global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<C>* __restrict__ in, XYZZ<C>* __restrict__ out, uint32_t per_in, uint32_t per_out,
                                uint32_t E) {
     __shared__ XYZZ<C> sh[256];
     const uint32_t tid = threadIdx.x;
@@ -399,7 +401,7 @@ __global__ void msm_sum_kernel(const XYZZ<C>* __restrict__ in, XYZZ<C>* __restri
 // out[i] = [k_i] G in affine form (k canonical).  Used to build seeded test / bench bases
 // (P_i = [k_i]G) and as the building block of fixed-base setup work.
 template <class C>
-__global__ void fixed_base_mul_kernel(const Fe<typename C::Fr>* __restrict__ scalars, Affine<C>* __restrict__ out, uint32_t n) {
+__global__ void __launch_bounds__(64) fixed_base_mul_kernel(const Fe<typename C::Fr>* __restrict__ scalars, Affine<C>* __restrict__ out, uint32_t n) {
     using Fr = typename C::Fr;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -1,0 +1,183 @@
+// NTT launch sequence (plan -> passes).  Included by zk_ntt_inst.cc, once per scalar field.
+#pragma once
+#include "zk_internal.h"
+namespace zk {
+// ------------------------------------------------------------------ NTT
+struct NttPlan {
+    int nd;
+    int rd[4];
+    int log_t[4];
+};
+
+// radix split: <= 10 bits per pass (R*T*32 B of LDS: 1024 x 2 = 64 KiB, 512 x 4 = 64 KiB)
+inline NttPlan ntt_plan(uint32_t logn) {
+    NttPlan p;
+    memset(&p, 0, sizeof p);
+    int max_r = 10;
+    if (const char* e = getenv("ZK_NTT_MAX_LOGR")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= 10) max_r = v;
+    }
+    int nd = (int)((logn + max_r - 1) / max_r);
+    if (nd < 1) nd = 1;
+    p.nd = nd;
+    int rem = (int)logn;
+    for (int i = 0; i < nd; i++) {
+        int r = (rem + (nd - i) - 1) / (nd - i);
+        p.rd[i] = r;
+        rem -= r;
+    }
+    int want_t = 2;
+    if (const char* e = getenv("ZK_NTT_LOGT")) {
+        int v = atoi(e);
+        if (v >= 0 && v <= 4) want_t = v;
+    }
+    int log_m = 0;
+    for (int i = 0; i < nd; i++) {
+        int lt = want_t;
+        if (p.rd[i] + lt > 11) lt = 11 - p.rd[i];  // <= 2048 elements = 64 KiB per tile
+        if (i < nd - 1) {
+            int log_s = (int)logn - log_m - p.rd[i];
+            if (lt > log_s) lt = log_s;
+        } else {
+            if (nd == 1) lt = 0;
+            else if (lt > p.rd[0]) lt = p.rd[0];
+        }
+        if (lt < 0) lt = 0;
+        p.log_t[i] = lt;
+        log_m += p.rd[i];
+    }
+    return p;
+}
+
+template <class F>
+int tw_table(const Fe<F>& omega, uint32_t logn, int field, hipStream_t st, const Fe<F>** out) {
+    TwKey key;
+    memset(&key, 0, sizeof key);
+    key.field = field;
+    key.logn = logn;
+    memcpy(key.omega, omega.v, sizeof(uint32_t) * F::N);
+    auto it = g.tw.find(key);
+    if (it != g.tw.end()) {
+        it->second.stamp = ++g.tw_stamp;
+        *out = (const Fe<F>*)it->second.dev;
+        return ZK_OK;
+    }
+    // evict least-recently-used tables beyond 8 entries / 2 GiB
+    while (g.tw.size() >= 8 || g.tw_bytes > (2ull << 30)) {
+        auto victim = g.tw.begin();
+        for (auto i2 = g.tw.begin(); i2 != g.tw.end(); ++i2)
+            if (i2->second.stamp < victim->second.stamp) victim = i2;
+        HIP_TRY(hipStreamSynchronize(st));
+        hipFree(victim->second.dev);
+        g.tw_bytes -= victim->second.bytes;
+        g.tw.erase(victim);
+    }
+    const uint64_t count = logn > 0 ? (1ull << (logn - 1)) : 1;
+    const int nbits = logn > 0 ? (int)logn - 1 : 0;
+    // tbl[k] = omega^(2^k)
+    std::vector<Fe<F>> tbl((size_t)(nbits > 0 ? nbits : 1));
+    Fe<F> w = omega;
+    for (int k = 0; k < nbits; k++) {
+        tbl[k] = w;
+        fe_sqr(w, w);
+    }
+    ZK_TRY(ws_get(g.pow_tbl, sizeof(Fe<F>) * 64));
+    HIP_TRY(hipMemcpyAsync(g.pow_tbl.p, tbl.data(), sizeof(Fe<F>) * tbl.size(), hipMemcpyHostToDevice, st));
+    void* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, sizeof(Fe<F>) * count));
+    const unsigned blk = 256;
+    ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((count + blk - 1) / blk), blk, 0, st, (Fe<F>*)dev, (const Fe<F>*)g.pow_tbl.p,
+              count, nbits);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // pow_tbl is reused by the next table build
+    TwEntry e{dev, sizeof(Fe<F>) * count, ++g.tw_stamp};
+    g.tw[key] = e;
+    g.tw_bytes += e.bytes;
+    *out = (const Fe<F>*)dev;
+    return ZK_OK;
+}
+
+template <class F>
+int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st) {
+    if (logn == 0) return ZK_OK;  // size-1 transform is the identity, and n^-1 = 1
+    if (logn > (uint32_t)F::TWO_ADICITY || logn > 30) return ZK_ERR_INVALID_ARG;
+    const Fe<F>* tw = nullptr;
+    ZK_TRY(tw_table<F>(omega, logn, field, st, &tw));
+    Fe<F> scale;
+    fe_one(scale);
+    if (scale_flag) {
+        Fe<F> nn;
+        fe_zero(nn);
+        nn.v[logn / 32] = 1u << (logn % 32);
+        fe_to_mont(nn, nn);
+        fe_inv(scale, nn);
+    }
+    NttPlan plan = ntt_plan(logn);
+    Fe<F>* tmp = nullptr;
+    if (plan.nd > 1) {
+        ZK_TRY(ws_get(g.ntt_tmp, sizeof(Fe<F>) << logn));
+        tmp = (Fe<F>*)g.ntt_tmp.p;
+    }
+    int log_m = 0;
+    for (int p = 0; p < plan.nd; p++) {
+        NttPass A;
+        memset(&A, 0, sizeof A);
+        A.logn = (int)logn;
+        A.log_m = log_m;
+        A.log_r = plan.rd[p];
+        A.log_t = plan.log_t[p];
+        A.last = (p == plan.nd - 1);
+        A.scale = A.last ? scale_flag : 0;
+        A.nd = plan.nd;
+        for (int i = 0; i < plan.nd; i++) A.rd[i] = plan.rd[i];
+        const Fe<F>* src;
+        Fe<F>* dst;
+        if (plan.nd == 1) {
+            src = a;
+            dst = a;
+        } else if (p == 0) {
+            src = a;
+            dst = tmp;
+        } else if (A.last) {
+            src = tmp;
+            dst = a;
+        } else {
+            src = tmp;
+            dst = tmp;
+        }
+        const uint64_t tiles = (1ull << logn) >> (A.log_r + A.log_t);
+        const uint32_t rt = 1u << (A.log_r + A.log_t);
+        unsigned blk = rt / 2 < 64 ? 64 : (rt / 2 > 256 ? 256 : rt / 2);
+        const size_t shmem = (size_t)rt * sizeof(Fe<F>);
+        if (shmem > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        ZK_LAUNCH((ntt_pass_kernel<F>), (unsigned)tiles, blk, shmem, st, src, dst, tw, A, scale);
+        HIP_TRY(hipGetLastError());
+        log_m += plan.rd[p];
+    }
+    return ZK_OK;
+}
+
+template <class F>
+int coset_run(Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st) {
+    if (logn > 30) return ZK_ERR_INVALID_ARG;
+    const uint64_t count = 1ull << logn;
+    std::vector<Fe<F>> tbl(logn ? logn : 1);
+    Fe<F> w = gshift;
+    for (uint32_t k = 0; k < logn; k++) {
+        tbl[k] = w;
+        fe_sqr(w, w);
+    }
+    ZK_TRY(ws_get(g.pow_tbl, sizeof(Fe<F>) * 64));
+    HIP_TRY(hipMemcpyAsync(g.pow_tbl.p, tbl.data(), sizeof(Fe<F>) * tbl.size(), hipMemcpyHostToDevice, st));
+    const unsigned blk = 256;
+    ZK_LAUNCH((coset_mul_kernel<F>), (unsigned)((count + blk - 1) / blk), blk, 0, st, a, (const Fe<F>*)g.pow_tbl.p, count,
+              (int)logn);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // pow_tbl reuse
+    return ZK_OK;
+}
+
+}  // namespace zk
