@@ -78,8 +78,8 @@ def main():
     d_a = torch.from_numpy(a_host.view(np.int64)).cuda()
     omega = zk.root_of_unity(sfield, args.logn)
 
-    prof_acc = {"accumulate_ms": 0.0, "total_ms": 0.0, "reduce_ms": 0.0, "digits_hist_ms": 0.0, "scatter_ms": 0.0,
-                "scan_ms": 0.0, "host_tail_ms": 0.0}
+    prof_acc = {"accumulate_ms": 0.0, "total_ms": 0.0, "reduce_ms": 0.0, "digits_ms": 0.0, "scatter_ms": 0.0,
+                "hist_ms": 0.0, "host_tail_ms": 0.0}
     ntt_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     result = {}
 

@@ -45,7 +45,7 @@ class MsmOpts(ctypes.Structure):
 
 
 class MsmProfile(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_float) for k in ("digits_hist_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms",
+    _fields_ = [(k, ctypes.c_float) for k in ("digits_ms", "hist_ms", "scatter_ms", "accumulate_ms", "reduce_ms",
                                               "host_tail_ms", "total_ms")] + \
                [(k, ctypes.c_int) for k in ("window_bits", "windows_total", "windows_done")]
 

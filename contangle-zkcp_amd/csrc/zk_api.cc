@@ -9,10 +9,10 @@ using namespace zk;
 namespace zk {
 Ctx g;
 int msm_pick_c(uint64_t n, int requested) {
-    if (requested > 0) return requested < 2 ? 2 : (requested > 20 ? 20 : requested);
+    if (requested > 0) return requested < 2 ? 2 : (requested > 16 ? 16 : requested);  // digits are stored as u16 codes
     if (const char* e = getenv("ZK_MSM_C")) {
         int v = atoi(e);
-        if (v >= 2 && v <= 20) return v;
+        if (v >= 2 && v <= 16) return v;
     }
     int l = 0;
     while ((1ull << l) < n) l++;
@@ -71,6 +71,7 @@ API int zk_init(int device_id) {
 #else
     snprintf(g.info, sizeof g.info, "hip %s %s cu=%d", prop.gcnArchName, prop.name, prop.multiProcessorCount);
 #endif
+    g.num_cus = prop.multiProcessorCount;
     g.device = device_id;
     g.inited = true;
     return ZK_OK;
@@ -86,7 +87,7 @@ API int zk_shutdown(void) {
     for (auto& kv : g.tw) hipFree(kv.second.dev);
     g.tw.clear();
     g.tw_bytes = 0;
-    for (DevBuf* b : {&g.ntt_tmp, &g.pow_tbl, &g.msm_counts, &g.msm_sorted, &g.msm_buckets, &g.msm_part_a, &g.msm_part_b,
+    for (DevBuf* b : {&g.ntt_tmp, &g.pow_tbl, &g.msm_counts, &g.msm_digits, &g.msm_queue, &g.msm_seg_out, &g.msm_sorted, &g.msm_buckets, &g.msm_part_a, &g.msm_part_b,
                       &g.scratch_in, &g.scratch_out})
         ws_free(*b);
     if (g.have_events) {

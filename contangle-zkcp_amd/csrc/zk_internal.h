@@ -64,6 +64,7 @@ struct Ctx {
     bool inited = false;
     int device = -1;
     int last_hip = 0;
+    int num_cus = 0;
     char info[256] = {0};
     std::map<uint64_t, BasesEntry> bases;
     uint64_t next_handle = 1;
@@ -71,7 +72,7 @@ struct Ctx {
     uint64_t tw_stamp = 0;
     size_t tw_bytes = 0;
     // workspaces (grow-only, reused across calls)
-    DevBuf ntt_tmp, pow_tbl, msm_counts, msm_sorted, msm_buckets, msm_part_a, msm_part_b, scratch_in, scratch_out;
+    DevBuf ntt_tmp, pow_tbl, msm_counts, msm_digits, msm_queue, msm_seg_out, msm_sorted, msm_buckets, msm_part_a, msm_part_b, scratch_in, scratch_out;
     hipEvent_t ev[8];
     bool have_events = false;
     zk_msm_profile prof;

@@ -212,21 +212,29 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(const Fe<F>* __restrict__
 
 // ------------------------------------------------------------------------------------------
 // MSM: signed-digit Pippenger.
-//   1. msm_hist_kernel     scalar -> signed c-bit digits, per-(window, bucket) counts
-//   2. msm_scan_kernel     exclusive prefix over the counts
-//   3. msm_scatter_kernel  counting-sort scatter of (point index | sign) by (window, bucket)
-//   4. msm_accumulate_kernel  one lane per bucket, XYZZ mixed adds over its sorted slice
-//   5. msm_reduce_kernel   sum_b b*B_b by slices: X_t = W_t + [t*L] S_t
-//   6. msm_sum_kernel      per-window tree sums of X_t
+//   1. msm_digits_kernel     scalar -> W signed c-bit digits, stored as u16 codes, window-major
+//   2. msm_hist_kernel       one workgroup per (window, bucket range): LDS histogram of its range
+//   3. msm_scatter_kernel    same grid: LDS scan -> bucket offsets, size-ordered bucket list, and the
+//                            counting-sort scatter of (point index | sign) through LDS cursors
+//   4. msm_accumulate_kernel one lane per bucket (largest first), XYZZ mixed adds over its slice
+//   5. msm_reduce_kernel     sum_b b*B_b by slices: X_t = W_t + [t*L] S_t
+//   6. msm_sum_kernel        per-window tree sums of X_t
 //   host: <= a few points per window, Horner over windows (c doublings each).
-// Digits are in [-2^(c-1), 2^(c-1)]; bucket b in 1..2^(c-1) holds sum of (+-)P_i with |digit| = b.
+// Digits are in [-(2^(c-1)-1), 2^(c-1)]; bucket index b-1 (b = |digit| in 1..2^(c-1)) holds the sum of
+// (+-)P_i.  No global atomics: every counter lives in the LDS of the workgroup that owns its bucket
+// range, and each workgroup scatters into its own contiguous slice of the sorted array (so the
+// 4-byte scattered stores combine in that XCD's L2 before they reach HBM).
 // ------------------------------------------------------------------------------------------
 struct MsmShape {
     uint32_t n;
-    int c;            // window bits
+    uint32_t n_pad;   // digit row stride (u16 elements), multiple of 8 so rows are 16-byte aligned
+    int c;            // window bits (<= 16)
     int w0, nw;       // this call accumulates windows [w0, w0 + nw) of the scalar (window-range sharding)
     uint32_t nbk;     // buckets per window = 2^(c-1)
+    uint32_t rb;      // buckets per workgroup range
+    uint32_t nranges; // ranges per window = nbk / rb
     int mont;         // scalars arrive in Montgomery form (halo2) rather than canonical (ark BigInt)
+    uint32_t big_thresh;  // buckets longer than this take the cooperative path
 };
 
 template <int N>
@@ -244,94 +252,281 @@ __device__ __forceinline__ uint32_t bits_at(const uint32_t (&s)[N], int start, i
     return (uint32_t)(v >> off) & ((1u << c) - 1);
 }
 
-template <class Fr>
-__device__ __forceinline__ void load_scalar(uint32_t (&s)[Fr::N], const Fe<Fr>* __restrict__ scalars, uint32_t i, int mont) {
-    Fe<Fr> x = scalars[i];
-    if (mont) fe_from_mont(x, x);
-    ZK_UNROLL
-    for (int k = 0; k < Fr::N; k++) s[k] = x.v[k];
-}
-
-// visits every non-zero digit of windows [w0, w0+nw): f(window_local, bucket_index(0-based), negative)
-template <class Fr, class Fn>
-__device__ __forceinline__ void for_each_digit(const uint32_t (&s)[Fr::N], const MsmShape& sh, Fn&& f) {
-    uint32_t carry = 0;
-    for (int w = 0; w < sh.w0 + sh.nw; w++) {
-        uint32_t raw = bits_at<Fr::N>(s, w * sh.c, sh.c) + carry;
-        bool neg = raw > sh.nbk;
-        uint32_t mag = neg ? (1u << sh.c) - raw : raw;
-        carry = neg ? 1u : 0u;
-        if (w >= sh.w0 && mag != 0) f(w - sh.w0, mag - 1, neg);
-    }
+// u16 digit code: two's complement of the signed digit; positive magnitudes reach 2^15 (0x8000),
+// negative ones only 2^15 - 1, so the code is unambiguous:  neg <=> code > 0x8000.
+__device__ __forceinline__ uint32_t digit_mag(uint32_t code, bool& neg) {
+    neg = code > 0x8000u;
+    return neg ? 0x10000u - code : code;
 }
 
 template <class C>
-__global__ void __launch_bounds__(256) msm_hist_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh, uint32_t* __restrict__ counts) {
+__global__ void __launch_bounds__(256) msm_digits_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh,
+                                                         uint16_t* __restrict__ digits) {
     using Fr = typename C::Fr;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sh.n) return;
-    uint32_t s[Fr::N];
-    load_scalar<Fr>(s, scalars, i, sh.mont);
-    for_each_digit<Fr>(s, sh, [&](int w, uint32_t b, bool) { atomicAdd(&counts[(uint32_t)w * sh.nbk + b], 1u); });
+    if (i >= sh.n_pad) return;
+    if (i >= sh.n) {  // row padding: zero digits
+        for (int w = 0; w < sh.nw; w++) digits[(uint64_t)w * sh.n_pad + i] = 0;
+        return;
+    }
+    Fe<Fr> x = scalars[i];
+    if (sh.mont) fe_from_mont(x, x);
+    uint32_t carry = 0;
+    for (int w = 0; w < sh.w0 + sh.nw; w++) {
+        const uint32_t raw = bits_at<Fr::N>(x.v, w * sh.c, sh.c) + carry;
+        const bool neg = raw > sh.nbk;
+        const uint32_t mag = neg ? (1u << sh.c) - raw : raw;
+        carry = neg ? 1u : 0u;
+        if (w >= sh.w0) digits[(uint64_t)(w - sh.w0) * sh.n_pad + i] = (uint16_t)(neg ? 0x10000u - mag : mag);
+    }
 }
 
-// offs[i] = sum_{k<i} counts[k]; single workgroup of 1024 lanes (template only so the header can be
-// included from several translation units)
+// visits every digit of window row `row` whose bucket falls in [lo, lo + rb): f(point index, bucket - lo, neg)
+template <class Fn>
+__device__ __forceinline__ void for_digits_in_range(const uint16_t* __restrict__ row, uint32_t n_pad, uint32_t lo, uint32_t rb,
+                                                    Fn&& f) {
+    const uint4* __restrict__ row4 = reinterpret_cast<const uint4*>(row);
+    const uint32_t nvec = n_pad >> 3;
+    for (uint32_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+        const uint4 q = row4[v];
+        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+        ZK_UNROLL
+        for (int k = 0; k < 8; k++) {
+            const uint32_t code = (wds[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+            bool neg;
+            const uint32_t mag = digit_mag(code, neg);
+            const uint32_t j = mag - 1 - lo;  // mag == 0 wraps to a huge value
+            if (j < rb) f(v * 8 + k, j, neg);
+        }
+    }
+}
+
+// grid = nw * nranges, workgroup (w, h) owns buckets [h*rb, (h+1)*rb) of window w
 template <class Tag>
-__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t m) {
-    __shared__ uint32_t part[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (m + 1023) / 1024;
-    const uint32_t lo = tid * per < m ? tid * per : m;
-    const uint32_t hi = lo + per < m ? lo + per : m;
+__global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restrict__ digits, MsmShape sh, uint32_t* __restrict__ counts,
+                                                        uint32_t* __restrict__ wg_total) {
+    ZK_DYN_SHARED(uint32_t, hist);  // rb counters (+ 1 total)
+    const uint32_t w = blockIdx.x / sh.nranges, h = blockIdx.x % sh.nranges;
+    const uint32_t lo = h * sh.rb;
+    for (uint32_t j = threadIdx.x; j <= sh.rb; j += blockDim.x) hist[j] = 0;
+    __syncthreads();
+    for_digits_in_range(digits + (uint64_t)w * sh.n_pad, sh.n_pad, lo, sh.rb,
+                        [&](uint32_t, uint32_t j, bool) { atomicAdd(&hist[j], 1u); });
+    __syncthreads();
+    uint32_t local = 0;
+    for (uint32_t j = threadIdx.x; j < sh.rb; j += blockDim.x) {
+        const uint32_t v = hist[j];
+        counts[(uint64_t)w * sh.nbk + lo + j] = v;
+        local += v;
+    }
+    atomicAdd(&hist[sh.rb], local);
+    __syncthreads();
+    if (threadIdx.x == 0) wg_total[blockIdx.x] = hist[sh.rb];
+}
+
+// same grid.  LDS: cur[rb] | part[1024] | bins[258]
+template <class Tag>
+__global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits, MsmShape sh,
+                                                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ wg_total,
+                                                           uint32_t* __restrict__ offs, uint32_t* __restrict__ order,
+                                                           uint32_t* __restrict__ sorted) {
+    ZK_DYN_SHARED(uint32_t, lds);
+    uint32_t* cur = lds;
+    uint32_t* part = lds + sh.rb;
+    uint32_t* bins = part + 1024;
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint32_t w = blockIdx.x / sh.nranges, h = blockIdx.x % sh.nranges;
+    const uint32_t lo = h * sh.rb;
+    const uint64_t gb0 = (uint64_t)w * sh.nbk + lo;
+    // base = number of entries owned by the workgroups before this one
+    uint32_t s = 0;
+    for (uint32_t g = tid; g < blockIdx.x; g += nth) s += wg_total[g];
+    part[tid] = s;
+    for (uint32_t j = tid; j < 258; j += nth) bins[j] = 0;
+    __syncthreads();
+    for (uint32_t d = nth >> 1; d > 0; d >>= 1) {
+        if (tid < d) part[tid] += part[tid + d];
+        __syncthreads();
+    }
+    const uint32_t base = part[0];
+    __syncthreads();
+    // exclusive scan of this range's counts: per-lane chunk sums, Hillis-Steele over the lanes, then refill
+    const uint32_t per = (sh.rb + nth - 1) / nth;
+    const uint32_t jlo = tid * per < sh.rb ? tid * per : sh.rb;
+    const uint32_t jhi = jlo + per < sh.rb ? jlo + per : sh.rb;
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += counts[i];
+    for (uint32_t j = jlo; j < jhi; j++) sum += counts[gb0 + j];
     part[tid] = sum;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = tid >= d ? part[tid - d] : 0;
+    for (uint32_t d = 1; d < nth; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0;
         __syncthreads();
         part[tid] += v;
         __syncthreads();
     }
-    uint32_t run = part[tid] - sum;
-    for (uint32_t i = lo; i < hi; i++) {
-        offs[i] = run;
-        run += counts[i];
+    uint32_t run = base + part[tid] - sum;
+    for (uint32_t j = jlo; j < jhi; j++) {
+        const uint32_t cnt = counts[gb0 + j];
+        cur[j] = run;
+        offs[gb0 + j] = run;
+        run += cnt;
+        atomicAdd(&bins[255u - (cnt < 255u ? cnt : 255u)], 1u);  // size classes, largest first
     }
-}
-
-template <class C>
-__global__ void __launch_bounds__(256) msm_scatter_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ offs,
-                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-    using Fr = typename C::Fr;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sh.n) return;
-    uint32_t s[Fr::N];
-    load_scalar<Fr>(s, scalars, i, sh.mont);
-    for_each_digit<Fr>(s, sh, [&](int w, uint32_t b, bool neg) {
-        const uint32_t gb = (uint32_t)w * sh.nbk + b;
-        const uint32_t p = offs[gb] + atomicAdd(&cursor[gb], 1u);
+    __syncthreads();
+    // order[]: the buckets of this range sorted by descending size class, so that the 64 buckets a wave of the
+    // accumulate kernel works on have (nearly) equal lengths
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < 256; k++) {
+            const uint32_t v = bins[k];
+            bins[k] = acc;
+            acc += v;
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = jlo; j < jhi; j++) {
+        const uint32_t cnt = counts[gb0 + j];
+        const uint32_t r = atomicAdd(&bins[255u - (cnt < 255u ? cnt : 255u)], 1u);
+        order[gb0 + r] = (uint32_t)(gb0 + j);
+    }
+    // scatter
+    for_digits_in_range(digits + (uint64_t)w * sh.n_pad, sh.n_pad, lo, sh.rb, [&](uint32_t i, uint32_t j, bool neg) {
+        const uint32_t p = atomicAdd(&cur[j], 1u);
         sorted[p] = i | (neg ? 0x80000000u : 0u);
     });
 }
 
+// Bucket accumulation: persistent waves pulling 64-bucket tasks from a queue, largest size class first
+// (longest-processing-time order, so the SIMDs finish together).  Task t = (rank r, range g): lane l sums
+// bucket order[g*rb + 64 r + l].  Buckets longer than sh.big_thresh (a few times the mean length: skewed
+// witnesses, e.g. the 25% of unit scalars of a Groth16 assignment) are not summed by one lane: they are cut
+// into segments of MSM_SEG entries appended to `seg_list` for msm_accumulate_big_kernel.
+constexpr uint32_t MSM_SEG = 2048;   // entries per cooperative segment (one wave: <= 32 adds per lane + a 6-level tree)
+
+struct MsmQueue {          // device-side control words, zeroed before every MSM
+    uint32_t head;         // next task
+    uint32_t nseg;         // segments appended
+    uint32_t nbig;         // big buckets appended
+    uint32_t pad;
+};
+struct MsmSeg {
+    uint32_t bucket, start, len, big_index;
+};
+
 template <class C>
-__global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                      const uint32_t* __restrict__ offs, const uint32_t* __restrict__ counts,
-                                      XYZZ<C>* __restrict__ buckets, uint32_t nbuckets) {
-    const uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gb >= nbuckets) return;
-    const uint32_t start = offs[gb], cnt = counts[gb];
-    XYZZ<C> acc;
-    xyzz_set_inf(acc);
-    for (uint32_t k = 0; k < cnt; k++) {
+__device__ __forceinline__ void accumulate_slice(XYZZ<C>& acc, const Affine<C>* __restrict__ bases,
+                                                 const uint32_t* __restrict__ sorted, uint32_t start, uint32_t cnt,
+                                                 uint32_t stride) {
+    for (uint32_t k = 0; k < cnt; k += stride) {
         const uint32_t e = sorted[start + k];
         Affine<C> p = bases[e & 0x7fffffffu];
         aff_neg_if(p, (e >> 31) != 0);
         xyzz_add_mixed(acc, p);
     }
-    buckets[gb] = acc;
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                      const uint32_t* __restrict__ offs, const uint32_t* __restrict__ counts,
+                                      const uint32_t* __restrict__ order, XYZZ<C>* __restrict__ buckets, MsmShape sh,
+                                      MsmQueue* __restrict__ q, MsmSeg* __restrict__ seg_list, uint32_t* __restrict__ big_list) {
+    __shared__ uint32_t task;
+    const uint32_t nrt = (uint32_t)sh.nw * sh.nranges;             // ranges in this call
+    const uint32_t ranks = (sh.rb + 63) / 64;                      // tasks per range
+    const uint32_t ntasks = nrt * ranks;
+    for (;;) {
+        if (threadIdx.x == 0) task = atomicAdd(&q->head, 1u);
+        __syncthreads();
+        const uint32_t t = task;
+        __syncthreads();
+        if (t >= ntasks) break;                                     // every wave reaches this once the queue is drained
+        const uint32_t r = t / nrt, g = t % nrt;
+        const uint32_t slot = r * 64 + threadIdx.x;
+        if (slot >= sh.rb) continue;
+        const uint32_t gb = order[(uint64_t)g * sh.rb + slot];
+        const uint32_t start = offs[gb], cnt = counts[gb];
+        if (cnt > sh.big_thresh) {
+            const uint32_t ns = (cnt + MSM_SEG - 1) / MSM_SEG;
+            const uint32_t bi = atomicAdd(&q->nbig, 1u);
+            const uint32_t s0 = atomicAdd(&q->nseg, ns);
+            big_list[2 * bi] = gb;
+            big_list[2 * bi + 1] = s0;
+            for (uint32_t k = 0; k < ns; k++) {
+                MsmSeg sg;
+                sg.bucket = gb;
+                sg.start = start + k * MSM_SEG;
+                sg.len = (k + 1 == ns) ? cnt - k * MSM_SEG : MSM_SEG;
+                sg.big_index = bi;
+                seg_list[s0 + k] = sg;
+            }
+            continue;
+        }
+        XYZZ<C> acc;
+        xyzz_set_inf(acc);
+        accumulate_slice<C>(acc, bases, sorted, start, cnt, 1);
+        buckets[gb] = acc;
+    }
+}
+
+// One wave per segment of an oversized bucket: lane-strided partial sums + LDS tree.
+// Fixed grid; waves stride over the device-side segment list.
+template <class C>
+__global__ void __launch_bounds__(64) msm_accumulate_big_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                                const MsmQueue* __restrict__ q, const MsmSeg* __restrict__ seg_list,
+                                                                XYZZ<C>* __restrict__ seg_out) {
+    __shared__ XYZZ<C> sh[64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nseg = q->nseg;
+    for (uint32_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const MsmSeg sg = seg_list[s];
+        XYZZ<C> acc;
+        xyzz_set_inf(acc);
+        if (tid < sg.len) accumulate_slice<C>(acc, bases, sorted, sg.start + tid, sg.len - tid, 64);
+        sh[tid] = acc;
+        __syncthreads();
+        for (uint32_t d = 32; d > 0; d >>= 1) {
+            if (tid < d) {
+                XYZZ<C> b = sh[tid + d];
+                xyzz_add(acc, b);
+                sh[tid] = acc;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) seg_out[s] = acc;
+        __syncthreads();
+    }
+}
+
+// bucket = sum of its segments (one workgroup per oversized bucket; segment counts are small: cnt / MSM_SEG)
+template <class C>
+__global__ void __launch_bounds__(256) msm_combine_big_kernel(const MsmQueue* __restrict__ q, const uint32_t* __restrict__ big_list,
+                                                              const uint32_t* __restrict__ counts, const XYZZ<C>* __restrict__ seg_out,
+                                                              XYZZ<C>* __restrict__ buckets) {
+    __shared__ XYZZ<C> sh[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nbig = q->nbig;
+    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const uint32_t gb = big_list[2 * b], s0 = big_list[2 * b + 1];
+        const uint32_t ns = (counts[gb] + MSM_SEG - 1) / MSM_SEG;
+        XYZZ<C> acc;
+        xyzz_set_inf(acc);
+        for (uint32_t k = tid; k < ns; k += 256) {
+            XYZZ<C> v = seg_out[s0 + k];
+            xyzz_add(acc, v);
+        }
+        sh[tid] = acc;
+        __syncthreads();
+        for (uint32_t d = 128; d > 0; d >>= 1) {
+            if (tid < d) {
+                XYZZ<C> v = sh[tid + d];
+                xyzz_add(acc, v);
+                sh[tid] = acc;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) buckets[gb] = acc;
+        __syncthreads();
+    }
 }
 
 // slice t of window w covers bucket indices [t*L, (t+1)*L) (weights index+1):

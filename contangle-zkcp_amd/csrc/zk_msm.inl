@@ -30,17 +30,32 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         if (n >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
         MsmShape sh;
         sh.n = (uint32_t)n;
+        sh.n_pad = (uint32_t)((n + 7) & ~7ull);
         sh.c = c;
         sh.w0 = w0;
         sh.nw = w1 - w0;
         sh.nbk = 1u << (c - 1);
+        sh.rb = sh.nbk < 2048u ? sh.nbk : 2048u;
+        sh.nranges = sh.nbk / sh.rb;
         sh.mont = mont;
+        {   // oversize threshold: 2x the mean bucket length + 64 (uniform 2^20 / c=16: mean 32, max ~70 -> none)
+            const uint64_t mean = n / sh.nbk;
+            sh.big_thresh = (uint32_t)(2 * mean + 64);
+            if (const char* e = getenv("ZK_MSM_BIG")) {
+                int v = atoi(e);
+                if (v >= 1) sh.big_thresh = (uint32_t)v;
+            }
+        }
         const uint32_t nbuckets = (uint32_t)sh.nw * sh.nbk;
-        // counts | offs | cursor
-        ZK_TRY(ws_get(g.msm_counts, (size_t)nbuckets * 4 * 3));
+        const uint32_t nwg = (uint32_t)sh.nw * sh.nranges;
+        // counts | offs | order | wg_total
+        ZK_TRY(ws_get(g.msm_counts, ((size_t)nbuckets * 3 + nwg) * 4));
         uint32_t* counts = (uint32_t*)g.msm_counts.p;
         uint32_t* offs = counts + nbuckets;
-        uint32_t* cursor = offs + nbuckets;
+        uint32_t* order = offs + nbuckets;
+        uint32_t* wg_total = order + nbuckets;
+        ZK_TRY(ws_get(g.msm_digits, (size_t)sh.n_pad * sh.nw * 2));
+        uint16_t* digits = (uint16_t*)g.msm_digits.p;
         ZK_TRY(ws_get(g.msm_sorted, (size_t)n * sh.nw * 4));
         ZK_TRY(ws_get(g.msm_buckets, (size_t)nbuckets * sizeof(XYZZ<C>)));
         uint32_t L = 8;
@@ -58,18 +73,41 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
             g.have_events = true;
         }
         const unsigned blk = 256;
+        const unsigned sblk = sh.n_pad >= 8192 ? 1024 : 256;  // lanes of the per-range sort workgroups (power of two)
         HIP_TRY(hipEventRecord(g.ev[0], st));
-        HIP_TRY(hipMemsetAsync(counts, 0, (size_t)nbuckets * 4 * 3, st));
-        ZK_LAUNCH((msm_hist_kernel<C>), (unsigned)((n + blk - 1) / blk), blk, 0, st, d_scalars, sh, counts);
+        ZK_LAUNCH((msm_digits_kernel<C>), (unsigned)((sh.n_pad + blk - 1) / blk), blk, 0, st, d_scalars, sh, digits);
         HIP_TRY(hipEventRecord(g.ev[1], st));
-        ZK_LAUNCH((msm_scan_kernel<void>), 1, 1024, 0, st, (const uint32_t*)counts, offs, nbuckets);
+        ZK_LAUNCH((msm_hist_kernel<void>), nwg, sblk, (size_t)(sh.rb + 1) * 4, st, (const uint16_t*)digits, sh, counts, wg_total);
         HIP_TRY(hipEventRecord(g.ev[2], st));
-        ZK_LAUNCH((msm_scatter_kernel<C>), (unsigned)((n + blk - 1) / blk), blk, 0, st, d_scalars, sh, (const uint32_t*)offs,
-                  cursor, (uint32_t*)g.msm_sorted.p);
+        ZK_LAUNCH((msm_scatter_kernel<void>), nwg, sblk, (size_t)(sh.rb + 1024 + 258) * 4, st, (const uint16_t*)digits, sh,
+                  (const uint32_t*)counts, (const uint32_t*)wg_total, offs, order, (uint32_t*)g.msm_sorted.p);
         HIP_TRY(hipEventRecord(g.ev[3], st));
-        ZK_LAUNCH((msm_accumulate_kernel<C>), (nbuckets + 63) / 64, 64, 0, st, (const Affine<C>*)be.dev,
-                  (const uint32_t*)g.msm_sorted.p, (const uint32_t*)offs, (const uint32_t*)counts, (XYZZ<C>*)g.msm_buckets.p,
-                  nbuckets);
+        // persistent accumulate: 4 waves per SIMD pull 64-bucket tasks, largest first; oversized buckets go to the
+        // cooperative segment kernels (fixed grids over device-side lists, no host round trip)
+        // every oversized bucket has > big_thresh entries and yields ceil(cnt / MSM_SEG) segments
+        const size_t max_seg = (size_t)n * sh.nw / MSM_SEG + (size_t)n * sh.nw / sh.big_thresh + 2;
+        ZK_TRY(ws_get(g.msm_queue, sizeof(MsmQueue) + max_seg * sizeof(MsmSeg) + max_seg * 8));
+        MsmQueue* q = (MsmQueue*)g.msm_queue.p;
+        MsmSeg* seg_list = (MsmSeg*)(q + 1);
+        uint32_t* big_list = (uint32_t*)(seg_list + max_seg);
+        ZK_TRY(ws_get(g.msm_seg_out, max_seg * sizeof(XYZZ<C>)));
+        HIP_TRY(hipMemsetAsync(q, 0, sizeof(MsmQueue), st));
+        const uint32_t ntasks = nwg * ((sh.rb + 63) / 64);
+        unsigned waves_per_simd = 4;
+        if (const char* e = getenv("ZK_MSM_WAVES")) {
+            int v = atoi(e);
+            if (v >= 1 && v <= 8) waves_per_simd = (unsigned)v;
+        }
+        unsigned acc_grid = (g.num_cus > 0 ? (unsigned)g.num_cus : 256u) * 4u * waves_per_simd;
+        if (acc_grid > ntasks) acc_grid = ntasks;
+        ZK_LAUNCH((msm_accumulate_kernel<C>), acc_grid, 64, 0, st, (const Affine<C>*)be.dev, (const uint32_t*)g.msm_sorted.p,
+                  (const uint32_t*)offs, (const uint32_t*)counts, (const uint32_t*)order, (XYZZ<C>*)g.msm_buckets.p, sh, q, seg_list,
+                  big_list);
+        const unsigned big_grid = max_seg < 4096 ? (unsigned)max_seg : 4096u;
+        ZK_LAUNCH((msm_accumulate_big_kernel<C>), big_grid, 64, 0, st, (const Affine<C>*)be.dev, (const uint32_t*)g.msm_sorted.p,
+                  (const MsmQueue*)q, (const MsmSeg*)seg_list, (XYZZ<C>*)g.msm_seg_out.p);
+        ZK_LAUNCH((msm_combine_big_kernel<C>), big_grid < 64 ? big_grid : 64u, 256, 0, st, (const MsmQueue*)q, (const uint32_t*)big_list,
+                  (const uint32_t*)counts, (const XYZZ<C>*)g.msm_seg_out.p, (XYZZ<C>*)g.msm_buckets.p);
         HIP_TRY(hipEventRecord(g.ev[4], st));
         ZK_LAUNCH((msm_reduce_kernel<C>), (nslices + 63) / 64, 64, 0, st, (const XYZZ<C>*)g.msm_buckets.p,
                   (XYZZ<C>*)g.msm_part_a.p, sh.nbk, L, spw, nslices);
@@ -100,8 +138,8 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         }
         for (int k = 0; k < c * w0; k++) xyzz_dbl(total);
         g.prof.host_tail_ms = (float)(now_ms() - t0);
-        hipEventElapsedTime(&g.prof.digits_hist_ms, g.ev[0], g.ev[1]);
-        hipEventElapsedTime(&g.prof.scan_ms, g.ev[1], g.ev[2]);
+        hipEventElapsedTime(&g.prof.digits_ms, g.ev[0], g.ev[1]);
+        hipEventElapsedTime(&g.prof.hist_ms, g.ev[1], g.ev[2]);
         hipEventElapsedTime(&g.prof.scatter_ms, g.ev[2], g.ev[3]);
         hipEventElapsedTime(&g.prof.accumulate_ms, g.ev[3], g.ev[4]);
         hipEventElapsedTime(&g.prof.reduce_ms, g.ev[4], g.ev[5]);

@@ -73,7 +73,7 @@ typedef struct {
 
 /* Wall-clock of the phases of the last zk_msm* call on this process (milliseconds, HIP events). */
 typedef struct {
-    float digits_hist_ms, scan_ms, scatter_ms, accumulate_ms, reduce_ms, host_tail_ms, total_ms;
+    float digits_ms, hist_ms, scatter_ms, accumulate_ms, reduce_ms, host_tail_ms, total_ms;
     int window_bits, windows_total, windows_done;
 } zk_msm_profile;
 

@@ -47,6 +47,10 @@ void syncthreads();
 #define ZK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     emu::launch((unsigned)(grid), (unsigned)(block), (size_t)(shmem), [&]() { (ZK_EMU_STRIP_PARENS kernel)(__VA_ARGS__); })
 
+struct alignas(16) uint4 {
+    uint32_t x, y, z, w;
+};
+
 template <class T>
 static inline T atomicAdd(T* p, T v) {
     T o = *p;

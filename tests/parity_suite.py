@@ -208,3 +208,19 @@ def check_msm_edges(zk, cname):
     bases = zk.Bases(cname, np.zeros((n, 2 * nl), dtype=np.uint64))
     assert not affine_of(zk, cname, zk.msm(bases, sc)).any()
     bases.free()
+
+
+def check_msm_big_buckets(zk, cname, n=5200, window_bits=6):
+    """buckets far above the oversize threshold (2x mean + 64) and above one segment (2048): 45% of the scalars are 1, 45% are 3 and the rest random --
+    exercises the cooperative segment kernels."""
+    pts = bases_for(cname, n)
+    sc = scalars_for(cname, n, 77)
+    sel = np.arange(n) % 20
+    sc[sel < 9] = 0
+    sc[sel < 9, 0] = 1
+    sc[(sel >= 9) & (sel < 18)] = 0
+    sc[(sel >= 9) & (sel < 18), 0] = 3
+    bases = zk.Bases(cname, pts)
+    got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
+    assert (got == orc.msm_ark(cname, pts, sc, threads=8)).all(), (cname, n)
+    bases.free()

@@ -65,3 +65,8 @@ def test_msm_vs_oracle(zk, cname, n, wb, realistic):
 def test_msm_window_sharding(zk):
     ps.check_msm_window_sharding(zk, "Vesta", 128, 6, 4)
     ps.check_msm_window_sharding(zk, "Bls381G1", 64, 5, 8)
+
+
+def test_msm_big_buckets(zk):
+    ps.check_msm_big_buckets(zk, "Vesta")
+    ps.check_msm_big_buckets(zk, "Bls381G1", n=2100, window_bits=4)

@@ -90,6 +90,12 @@ def test_msm_window_sharding(zk, cname, parts):
     ps.check_msm_window_sharding(zk, cname, 3000, 16, parts)
 
 
+@pytest.mark.parametrize("cname", ps.CURVES)
+def test_msm_big_buckets(zk, cname):
+    ps.check_msm_big_buckets(zk, cname)
+    ps.check_msm_big_buckets(zk, cname, n=9000, window_bits=13)
+
+
 def _device_bases(zk, cname, n, seed=77):
     """bases generated on the GPU: P_i = [k_i]G via zk_fixed_base_mul_device; spot-checked on the oracle."""
     import torch
