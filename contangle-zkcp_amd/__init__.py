@@ -19,9 +19,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libzkcp_amd.so")
 
 # zk_curve_t / zk_field_t
-PALLAS, VESTA, BN254_G1, BLS12_381_G1 = 0, 1, 2, 3
+PALLAS, VESTA, BN254_G1, BLS12_381_G1, BN254_G2, BLS12_381_G2 = 0, 1, 2, 3, 4, 5
 FP_PALLAS, FQ_PALLAS, FR_BN254, FR_BLS12_381 = 0, 1, 2, 3
-CURVE_NAMES = {"Pallas": PALLAS, "Vesta": VESTA, "Bn254G1": BN254_G1, "Bls381G1": BLS12_381_G1}
+CURVE_NAMES = {"Pallas": PALLAS, "Vesta": VESTA, "Bn254G1": BN254_G1, "Bls381G1": BLS12_381_G1,
+               "Bn254G2": BN254_G2, "Bls381G2": BLS12_381_G2}
 FIELD_NAMES = {"PallasFp": FP_PALLAS, "PallasFq": FQ_PALLAS, "Bn254Fr": FR_BN254, "Bls381Fr": FR_BLS12_381}
 
 EXPORTS = [

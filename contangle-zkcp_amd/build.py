@@ -14,7 +14,7 @@ LIB = os.path.join(PKG, "libzkcp_amd.so")
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libzkcp_emu.so")
 
-CURVES = ["Pallas", "Vesta", "Bn254G1", "Bls381G1"]
+CURVES = ["Pallas", "Vesta", "Bn254G1", "Bls381G1", "Bn254G2", "Bls381G2"]
 FIELDS = ["PallasFp", "PallasFq", "Bn254Fr", "Bls381Fr"]
 # (source, extra define, object tag)
 UNITS = [("zk_api.cc", None, "api")] + \

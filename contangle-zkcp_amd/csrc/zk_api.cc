@@ -112,7 +112,7 @@ API int zk_field_limbs64(zk_field_t f) {
     return ZK_ERR_INVALID_ARG;
 }
 API int zk_curve_base_limbs64(zk_curve_t c) {
-    CURVE_SWITCH(c, return C::Fq::N / 2);
+    CURVE_SWITCH(c, return coord_words<C>() / 2);
     return ZK_ERR_INVALID_ARG;
 }
 API int zk_curve_scalar_field(zk_curve_t c) {
@@ -121,6 +121,8 @@ API int zk_curve_scalar_field(zk_curve_t c) {
         case ZK_VESTA: return ZK_FP_PALLAS;
         case ZK_BN254_G1: return ZK_FR_BN254;
         case ZK_BLS12_381_G1: return ZK_FR_BLS12_381;
+        case ZK_BN254_G2: return ZK_FR_BN254;
+        case ZK_BLS12_381_G2: return ZK_FR_BLS12_381;
         default: return ZK_ERR_INVALID_ARG;
     }
 }
@@ -292,14 +294,14 @@ API int zk_point_add(zk_curve_t c, const void* ja, const void* jb, void* jout) {
     if (!ja || !jb || !jout) return ZK_ERR_INVALID_ARG;
     CURVE_SWITCH(c, {
         Jacobian<C> a, b, r;
-        memcpy(&a, ja, 3 * 4 * C::Fq::N);
-        memcpy(&b, jb, 3 * 4 * C::Fq::N);
+        memcpy(&a, ja, 3 * 4 * coord_words<C>());
+        memcpy(&b, jb, 3 * 4 * coord_words<C>());
         XYZZ<C> xa, xb;
         jac_to_xyzz(xa, a);
         jac_to_xyzz(xb, b);
         xyzz_add(xa, xb);
         xyzz_to_jacobian(r, xa);
-        memcpy(jout, &r, 3 * 4 * C::Fq::N);
+        memcpy(jout, &r, 3 * 4 * coord_words<C>());
     });
     return ZK_OK;
 }
@@ -307,12 +309,12 @@ API int zk_point_to_affine(zk_curve_t c, const void* jac, void* aff) {
     if (!jac || !aff) return ZK_ERR_INVALID_ARG;
     CURVE_SWITCH(c, {
         Jacobian<C> a;
-        memcpy(&a, jac, 3 * 4 * C::Fq::N);
+        memcpy(&a, jac, 3 * 4 * coord_words<C>());
         XYZZ<C> x;
         jac_to_xyzz(x, a);
         Affine<C> r;
         xyzz_to_affine(r, x);
-        memcpy(aff, &r, 2 * 4 * C::Fq::N);
+        memcpy(aff, &r, 2 * 4 * coord_words<C>());
     });
     return ZK_OK;
 }

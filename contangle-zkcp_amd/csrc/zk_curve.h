@@ -8,30 +8,44 @@
 //
 // Affine points are (x, y) Montgomery; infinity is encoded as (0, 0), which is never on
 // y^2 = x^3 + b for b != 0.
+//
+// The same formulas serve G1 (coordinates in Fq) and the G2 twists of BN254 / BLS12-381
+// (coordinates in Fq2): `Coord<C>` is Fe<Fq> or Fe2<Fq> and every fe_* below is an overload.
 #pragma once
+#include <type_traits>
+
 #include "zk_field.h"
 
 namespace zk {
 
 template <class C>
+using Coord = std::conditional_t<C::EXT == 2, Fe2<typename C::Fq>, Fe<typename C::Fq>>;
+template <class C>
+constexpr int coord_words() {
+    return C::EXT * C::Fq::N;
+}
+
+template <class C>
 struct Affine {
-    Fe<typename C::Fq> x, y;
+    Coord<C> x, y;
 };
 template <class C>
 struct XYZZ {
-    Fe<typename C::Fq> x, y, zz, zzz;
+    Coord<C> x, y, zz, zzz;
 };
 template <class C>
 struct Jacobian {
-    Fe<typename C::Fq> x, y, z;
+    Coord<C> x, y, z;
 };
 
 template <class C>
 ZK_HD bool aff_is_inf(const Affine<C>& p) {
-    uint32_t o = 0;
-    ZK_UNROLL
-    for (int i = 0; i < C::Fq::N; i++) o |= p.x.v[i] | p.y.v[i];
-    return o == 0;
+    return fe_is_zero(p.x) && fe_is_zero(p.y);
+}
+template <class C>
+ZK_HD void curve_generator(Affine<C>& g) {
+    fe_from_words(g.x, C::GX);
+    fe_from_words(g.y, C::GY);
 }
 template <class C>
 ZK_HD void xyzz_set_inf(XYZZ<C>& p) {
@@ -59,8 +73,7 @@ ZK_HD void xyzz_from_affine(XYZZ<C>& r, const Affine<C>& p) {
 // mdbl-2008-s-1: r = 2*(affine p), p != inf
 template <class C>
 ZK_HD void xyzz_dbl_affine(XYZZ<C>& r, const Affine<C>& p) {
-    using F = typename C::Fq;
-    Fe<F> u, v, w, s, m, t;
+    Coord<C> u, v, w, s, m, t;
     fe_dbl(u, p.y);
     fe_sqr(v, u);
     fe_mul(w, u, v);
@@ -82,9 +95,8 @@ ZK_HD void xyzz_dbl_affine(XYZZ<C>& r, const Affine<C>& p) {
 // dbl-2008-s-1: p = 2p
 template <class C>
 ZK_HD void xyzz_dbl(XYZZ<C>& p) {
-    using F = typename C::Fq;
     if (xyzz_is_inf(p)) return;
-    Fe<F> u, v, w, s, m, t, x3;
+    Coord<C> u, v, w, s, m, t, x3;
     fe_dbl(u, p.y);
     fe_sqr(v, u);
     fe_mul(w, u, v);
@@ -107,7 +119,6 @@ ZK_HD void xyzz_dbl(XYZZ<C>& p) {
 // madd-2008-s: acc += (affine q), all special cases handled
 template <class C>
 ZK_HD void xyzz_add_mixed(XYZZ<C>& acc, const Affine<C>& q) {
-    using F = typename C::Fq;
     if (aff_is_inf(q)) return;
     if (xyzz_is_inf(acc)) {
         acc.x = q.x;
@@ -116,7 +127,7 @@ ZK_HD void xyzz_add_mixed(XYZZ<C>& acc, const Affine<C>& q) {
         fe_one(acc.zzz);
         return;
     }
-    Fe<F> p, r, pp, ppp, qq, t;
+    Coord<C> p, r, pp, ppp, qq, t;
     fe_mul(p, q.x, acc.zz);
     fe_mul(r, q.y, acc.zzz);
     fe_sub(p, p, acc.x);
@@ -147,13 +158,12 @@ ZK_HD void xyzz_add_mixed(XYZZ<C>& acc, const Affine<C>& q) {
 // add-2008-s: acc += q (both XYZZ), all special cases handled
 template <class C>
 ZK_HD void xyzz_add(XYZZ<C>& acc, const XYZZ<C>& q) {
-    using F = typename C::Fq;
     if (xyzz_is_inf(q)) return;
     if (xyzz_is_inf(acc)) {
         acc = q;
         return;
     }
-    Fe<F> u1, u2, s1, s2, p, r, pp, ppp, qq, t;
+    Coord<C> u1, u2, s1, s2, p, r, pp, ppp, qq, t;
     fe_mul(u1, acc.x, q.zz);
     fe_mul(u2, q.x, acc.zz);
     fe_mul(s1, acc.y, q.zzz);
@@ -203,13 +213,12 @@ ZK_HD void xyzz_to_jacobian(Jacobian<C>& r, const XYZZ<C>& p) {
 // XYZZ -> affine (host-side: one Fermat inversion).  Identity -> (0, 0)
 template <class C>
 ZK_HD void xyzz_to_affine(Affine<C>& r, const XYZZ<C>& p) {
-    using F = typename C::Fq;
     if (xyzz_is_inf(p)) {
         fe_zero(r.x);
         fe_zero(r.y);
         return;
     }
-    Fe<F> izzz, izz, t;
+    Coord<C> izzz, izz, t;
     fe_inv(izzz, p.zzz);       // 1/z^3
     fe_mul(t, izzz, p.zz);     // 1/z
     fe_sqr(izz, t);            // 1/z^2
@@ -219,11 +228,10 @@ ZK_HD void xyzz_to_affine(Affine<C>& r, const XYZZ<C>& p) {
 
 template <class C>
 ZK_HD void aff_neg_if(Affine<C>& p, bool neg) {
-    // y -> p - y when neg (y != 0 for any finite point of odd-order groups; (0,0) stays (0,0) via the mask)
-    Fe<typename C::Fq> ny;
+    // y -> -y when neg; (0,0) stays (0,0)
+    Coord<C> ny;
     fe_neg(ny, p.y);
-    ZK_UNROLL
-    for (int i = 0; i < C::Fq::N; i++) p.y.v[i] = neg ? ny.v[i] : p.y.v[i];
+    fe_cmov(p.y, ny, neg);
 }
 
 }  // namespace zk

@@ -215,4 +215,109 @@ ZK_HD void fe_inv(Fe<P>& r, const Fe<P>& a) {
     r = acc;
 }
 
+// ------------------------------------------------------------------------------------------
+// Fq2 = Fq[u] / (u^2 + 1): the coordinate field of the G2 twists of BN254 and BLS12-381
+// (ark-ff 0.3 Fp2 with NONRESIDUE = -1).  Same free-function names as Fe<P>, so the curve
+// formulas in zk_curve.h are written once for both.
+// ------------------------------------------------------------------------------------------
+template <class P>
+struct Fe2 {
+    Fe<P> c0, c1;
+};
+template <class P>
+ZK_HD void fe_zero(Fe2<P>& r) {
+    fe_zero(r.c0);
+    fe_zero(r.c1);
+}
+template <class P>
+ZK_HD void fe_one(Fe2<P>& r) {
+    fe_one(r.c0);
+    fe_zero(r.c1);
+}
+template <class P>
+ZK_HD bool fe_is_zero(const Fe2<P>& a) {
+    return fe_is_zero(a.c0) && fe_is_zero(a.c1);
+}
+template <class P>
+ZK_HD bool fe_eq(const Fe2<P>& a, const Fe2<P>& b) {
+    return fe_eq(a.c0, b.c0) && fe_eq(a.c1, b.c1);
+}
+template <class P>
+ZK_HD void fe_add(Fe2<P>& r, const Fe2<P>& a, const Fe2<P>& b) {
+    fe_add(r.c0, a.c0, b.c0);
+    fe_add(r.c1, a.c1, b.c1);
+}
+template <class P>
+ZK_HD void fe_sub(Fe2<P>& r, const Fe2<P>& a, const Fe2<P>& b) {
+    fe_sub(r.c0, a.c0, b.c0);
+    fe_sub(r.c1, a.c1, b.c1);
+}
+template <class P>
+ZK_HD void fe_neg(Fe2<P>& r, const Fe2<P>& a) {
+    fe_neg(r.c0, a.c0);
+    fe_neg(r.c1, a.c1);
+}
+template <class P>
+ZK_HD void fe_dbl(Fe2<P>& r, const Fe2<P>& a) {
+    fe_dbl(r.c0, a.c0);
+    fe_dbl(r.c1, a.c1);
+}
+// Karatsuba: 3 base multiplications
+template <class P>
+ZK_HD void fe_mul(Fe2<P>& r, const Fe2<P>& a, const Fe2<P>& b) {
+    Fe<P> v0, v1, s, t;
+    fe_mul(v0, a.c0, b.c0);
+    fe_mul(v1, a.c1, b.c1);
+    fe_add(s, a.c0, a.c1);
+    fe_add(t, b.c0, b.c1);
+    fe_mul(s, s, t);
+    fe_sub(s, s, v0);
+    fe_sub(r.c1, s, v1);
+    fe_sub(r.c0, v0, v1);
+}
+// (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u: 2 base multiplications
+template <class P>
+ZK_HD void fe_sqr(Fe2<P>& r, const Fe2<P>& a) {
+    Fe<P> s, d, m;
+    fe_add(s, a.c0, a.c1);
+    fe_sub(d, a.c0, a.c1);
+    fe_mul(m, a.c0, a.c1);
+    fe_mul(r.c0, s, d);
+    fe_dbl(r.c1, m);
+}
+// 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2)
+template <class P>
+ZK_HD void fe_inv(Fe2<P>& r, const Fe2<P>& a) {
+    Fe<P> n, t;
+    fe_sqr(n, a.c0);
+    fe_sqr(t, a.c1);
+    fe_add(n, n, t);
+    fe_inv(n, n);
+    fe_mul(r.c0, a.c0, n);
+    fe_neg(t, a.c1);
+    fe_mul(r.c1, t, n);
+}
+// r = sel ? a : r  (branch-free limb select)
+template <class P>
+ZK_HD void fe_cmov(Fe<P>& r, const Fe<P>& a, bool sel) {
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) r.v[i] = sel ? a.v[i] : r.v[i];
+}
+template <class P>
+ZK_HD void fe_cmov(Fe2<P>& r, const Fe2<P>& a, bool sel) {
+    fe_cmov(r.c0, a.c0, sel);
+    fe_cmov(r.c1, a.c1, sel);
+}
+// load from little-endian u32 words (c0 words then c1 words for Fe2)
+template <class P>
+ZK_HD void fe_from_words(Fe<P>& r, const uint32_t* w) {
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) r.v[i] = w[i];
+}
+template <class P>
+ZK_HD void fe_from_words(Fe2<P>& r, const uint32_t* w) {
+    fe_from_words(r.c0, w);
+    fe_from_words(r.c1, w + P::N);
+}
+
 }  // namespace zk

@@ -118,6 +118,8 @@ void host_store(void* p, const Fe<F>& r) {
         case ZK_VESTA: { using C = Vesta; __VA_ARGS__; } break;              \
         case ZK_BN254_G1: { using C = Bn254G1; __VA_ARGS__; } break;         \
         case ZK_BLS12_381_G1: { using C = Bls381G1; __VA_ARGS__; } break;    \
+        case ZK_BN254_G2: { using C = Bn254G2; __VA_ARGS__; } break;         \
+        case ZK_BLS12_381_G2: { using C = Bls381G2; __VA_ARGS__; } break;    \
         default: return ZK_ERR_INVALID_ARG;                           \
     }
 

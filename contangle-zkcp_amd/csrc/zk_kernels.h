@@ -235,6 +235,7 @@ struct MsmShape {
     uint32_t nranges; // ranges per window = nbk / rb
     int mont;         // scalars arrive in Montgomery form (halo2) rather than canonical (ark BigInt)
     uint32_t big_thresh;  // buckets longer than this take the cooperative path
+    uint32_t idx_mask;    // 0x7fffffff; narrowed only by the ZK_MSM_DEBUG_MASK profiling experiment (wrong results!)
 };
 
 template <int N>
@@ -403,6 +404,12 @@ __global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __res
 // into segments of MSM_SEG entries appended to `seg_list` for msm_accumulate_big_kernel.
 constexpr uint32_t MSM_SEG = 2048;   // entries per cooperative segment (one wave: <= 32 adds per lane + a 6-level tree)
 
+// lanes per workgroup of the LDS tree kernels: 256 XYZZ points must fit the 64 KiB static LDS limit (G2: 384 B each)
+template <class C>
+constexpr uint32_t tree_lanes() {
+    return sizeof(XYZZ<C>) * 256 <= 48 * 1024 ? 256u : 128u;
+}
+
 struct MsmQueue {          // device-side control words, zeroed before every MSM
     uint32_t head;         // next task
     uint32_t nseg;         // segments appended
@@ -425,46 +432,91 @@ __device__ __forceinline__ void accumulate_slice(XYZZ<C>& acc, const Affine<C>* 
     }
 }
 
+// Persistent waves; every LANE streams buckets: when a lane finishes its bucket it takes the next one from the
+// wave's batch (LDS cursor), and the wave refills its batch from the global queue 64 buckets at a time.  Buckets
+// are visited largest size class first (rank-major over the per-range size-sorted lists), so the queue drains
+// into the shortest buckets and all SIMDs finish together; lanes never wait for a longer neighbour.
+constexpr uint32_t MSM_BATCH = 64;
+
 template <class C>
 __global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                       const uint32_t* __restrict__ offs, const uint32_t* __restrict__ counts,
                                       const uint32_t* __restrict__ order, XYZZ<C>* __restrict__ buckets, MsmShape sh,
                                       MsmQueue* __restrict__ q, MsmSeg* __restrict__ seg_list, uint32_t* __restrict__ big_list) {
-    __shared__ uint32_t task;
-    const uint32_t nrt = (uint32_t)sh.nw * sh.nranges;             // ranges in this call
-    const uint32_t ranks = (sh.rb + 63) / 64;                      // tasks per range
-    const uint32_t ntasks = nrt * ranks;
+    __shared__ uint32_t s_next, s_end;
+    const uint32_t nrt = (uint32_t)sh.nw * sh.nranges;                 // ranges in this call
+    const uint32_t per_rank = nrt * 64;                                // positions per size rank
+    const uint32_t total = ((sh.rb + 63) / 64) * per_rank;             // visiting positions (ranges padded to 64 slots)
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) {
+        s_next = 0;
+        s_end = 0;
+    }
+    __syncthreads();
+    bool have = false, drained = false;
+    uint32_t gb = 0, pos = 0, end = 0;
+    XYZZ<C> acc;
+    xyzz_set_inf(acc);
     for (;;) {
-        if (threadIdx.x == 0) task = atomicAdd(&q->head, 1u);
-        __syncthreads();
-        const uint32_t t = task;
-        __syncthreads();
-        if (t >= ntasks) break;                                     // every wave reaches this once the queue is drained
-        const uint32_t r = t / nrt, g = t % nrt;
-        const uint32_t slot = r * 64 + threadIdx.x;
-        if (slot >= sh.rb) continue;
-        const uint32_t gb = order[(uint64_t)g * sh.rb + slot];
-        const uint32_t start = offs[gb], cnt = counts[gb];
-        if (cnt > sh.big_thresh) {
-            const uint32_t ns = (cnt + MSM_SEG - 1) / MSM_SEG;
-            const uint32_t bi = atomicAdd(&q->nbig, 1u);
-            const uint32_t s0 = atomicAdd(&q->nseg, ns);
-            big_list[2 * bi] = gb;
-            big_list[2 * bi + 1] = s0;
-            for (uint32_t k = 0; k < ns; k++) {
-                MsmSeg sg;
-                sg.bucket = gb;
-                sg.start = start + k * MSM_SEG;
-                sg.len = (k + 1 == ns) ? cnt - k * MSM_SEG : MSM_SEG;
-                sg.big_index = bi;
-                seg_list[s0 + k] = sg;
+        // ---- lanes without a bucket take the next position of the wave's batch
+        bool want_refill = false;
+        if (!have && !drained) {
+            const uint32_t i = atomicAdd(&s_next, 1u);
+            if (i < s_end) {
+                const uint32_t r = i / per_rank, rem = i % per_rank;
+                const uint32_t g = rem / 64, slot = r * 64 + (rem % 64);
+                if (slot < sh.rb) {
+                    gb = order[(uint64_t)g * sh.rb + slot];
+                    const uint32_t start = offs[gb], cnt = counts[gb];
+                    if (cnt > sh.big_thresh) {
+                        const uint32_t ns = (cnt + MSM_SEG - 1) / MSM_SEG;
+                        const uint32_t bi = atomicAdd(&q->nbig, 1u);
+                        const uint32_t s0 = atomicAdd(&q->nseg, ns);
+                        big_list[2 * bi] = gb;
+                        big_list[2 * bi + 1] = s0;
+                        for (uint32_t k = 0; k < ns; k++) {
+                            MsmSeg sg;
+                            sg.bucket = gb;
+                            sg.start = start + k * MSM_SEG;
+                            sg.len = (k + 1 == ns) ? cnt - k * MSM_SEG : MSM_SEG;
+                            sg.big_index = bi;
+                            seg_list[s0 + k] = sg;
+                        }
+                    } else if (cnt == 0) {
+                        xyzz_set_inf(acc);
+                        buckets[gb] = acc;
+                    } else {
+                        have = true;
+                        pos = start;
+                        end = start + cnt;
+                        xyzz_set_inf(acc);
+                    }
+                }
+            } else {
+                want_refill = true;
             }
-            continue;
         }
-        XYZZ<C> acc;
-        xyzz_set_inf(acc);
-        accumulate_slice<C>(acc, bases, sorted, start, cnt, 1);
-        buckets[gb] = acc;
+        // ---- one mixed add for every lane that owns a bucket
+        if (have) {
+            const uint32_t e = sorted[pos];
+            Affine<C> p = bases[e & sh.idx_mask & 0x7fffffffu];
+            aff_neg_if(p, (e >> 31) != 0);
+            xyzz_add_mixed(acc, p);
+            if (++pos == end) {
+                buckets[gb] = acc;
+                have = false;
+            }
+        }
+        if (__syncthreads_count(want_refill) != 0) {   // wave-uniform
+            if (lane == 0) {
+                const uint32_t base = atomicAdd(&q->head, MSM_BATCH);
+                s_next = base < total ? base : total;
+                s_end = base + MSM_BATCH < total ? base + MSM_BATCH : total;
+            }
+            __syncthreads();
+            if (s_next >= s_end) drained = true;        // the global queue is empty: nothing left to take
+        }
+        if (__syncthreads_count(have || !drained) == 0) break;  // every lane has stored its last bucket
     }
 }
 
@@ -502,7 +554,8 @@ template <class C>
 __global__ void __launch_bounds__(256) msm_combine_big_kernel(const MsmQueue* __restrict__ q, const uint32_t* __restrict__ big_list,
                                                               const uint32_t* __restrict__ counts, const XYZZ<C>* __restrict__ seg_out,
                                                               XYZZ<C>* __restrict__ buckets) {
-    __shared__ XYZZ<C> sh[256];
+    constexpr uint32_t TL = tree_lanes<C>();
+    __shared__ XYZZ<C> sh[TL];
     const uint32_t tid = threadIdx.x;
     const uint32_t nbig = q->nbig;
     for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
@@ -510,13 +563,13 @@ __global__ void __launch_bounds__(256) msm_combine_big_kernel(const MsmQueue* __
         const uint32_t ns = (counts[gb] + MSM_SEG - 1) / MSM_SEG;
         XYZZ<C> acc;
         xyzz_set_inf(acc);
-        for (uint32_t k = tid; k < ns; k += 256) {
+        for (uint32_t k = tid; k < ns; k += TL) {
             XYZZ<C> v = seg_out[s0 + k];
             xyzz_add(acc, v);
         }
         sh[tid] = acc;
         __syncthreads();
-        for (uint32_t d = 128; d > 0; d >>= 1) {
+        for (uint32_t d = TL / 2; d > 0; d >>= 1) {
             if (tid < d) {
                 XYZZ<C> v = sh[tid + d];
                 xyzz_add(acc, v);
@@ -566,15 +619,16 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restric
 template <class C>
 __global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<C>* __restrict__ in, XYZZ<C>* __restrict__ out, uint32_t per_in, uint32_t per_out,
                                uint32_t E) {
-    __shared__ XYZZ<C> sh[256];
+    constexpr uint32_t TL = tree_lanes<C>();
+    __shared__ XYZZ<C> sh[TL];
     const uint32_t tid = threadIdx.x;
     const uint32_t s = blockIdx.x / per_out, o = blockIdx.x % per_out;
-    const uint32_t chunk = 256 * E;
+    const uint32_t chunk = TL * E;
     const uint32_t lo = o * chunk;
     XYZZ<C> acc;
     xyzz_set_inf(acc);
     for (uint32_t k = 0; k < E; k++) {
-        const uint32_t i = lo + k * 256 + tid;
+        const uint32_t i = lo + k * TL + tid;
         if (i < per_in && i < lo + chunk) {
             XYZZ<C> b = in[(uint64_t)s * per_in + i];
             xyzz_add(acc, b);
@@ -582,7 +636,7 @@ __global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<C>* __restrict_
     }
     sh[tid] = acc;
     __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
+    for (uint32_t d = TL / 2; d > 0; d >>= 1) {
         if (tid < d) {
             XYZZ<C> b = sh[tid + d];
             xyzz_add(acc, b);
@@ -602,11 +656,7 @@ __global__ void __launch_bounds__(64) fixed_base_mul_kernel(const Fe<typename C:
     if (i >= n) return;
     Fe<Fr> k = scalars[i];
     Affine<C> g;
-    ZK_UNROLL
-    for (int l = 0; l < C::Fq::N; l++) {
-        g.x.v[l] = C::GX[l];
-        g.y.v[l] = C::GY[l];
-    }
+    curve_generator(g);
     XYZZ<C> acc;
     xyzz_set_inf(acc);
     for (int bit = 32 * Fr::N - 1; bit >= 0; bit--) {

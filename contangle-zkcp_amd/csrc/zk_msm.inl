@@ -10,7 +10,6 @@ inline double now_ms() {
 template <class C>
 int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
             void* out_jac, hipStream_t st) {
-    using Fq = typename C::Fq;
     Jacobian<C> result;
     memset(&g.prof, 0, sizeof g.prof);
     XYZZ<C> total;
@@ -38,6 +37,8 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         sh.rb = sh.nbk < 2048u ? sh.nbk : 2048u;
         sh.nranges = sh.nbk / sh.rb;
         sh.mont = mont;
+        sh.idx_mask = 0x7fffffffu;
+        if (const char* e = getenv("ZK_MSM_DEBUG_MASK")) sh.idx_mask = (uint32_t)strtoul(e, nullptr, 0);  // profiling only
         {   // oversize threshold: 2x the mean bucket length + 64 (uniform 2^20 / c=16: mean 32, max ~70 -> none)
             const uint64_t mean = n / sh.nbk;
             sh.big_thresh = (uint32_t)(2 * mean + 64);
@@ -67,7 +68,7 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         const uint32_t spw = (sh.nbk + L - 1) / L;
         const uint32_t nslices = spw * (uint32_t)sh.nw;
         ZK_TRY(ws_get(g.msm_part_a, (size_t)nslices * sizeof(XYZZ<C>)));
-        ZK_TRY(ws_get(g.msm_part_b, ((size_t)nslices / 256 + (size_t)sh.nw + 8) * sizeof(XYZZ<C>)));
+        ZK_TRY(ws_get(g.msm_part_b, ((size_t)nslices / 128 + (size_t)sh.nw + 8) * sizeof(XYZZ<C>)));
         if (!g.have_events) {
             for (auto& e : g.ev) HIP_TRY(hipEventCreate(&e));
             g.have_events = true;
@@ -92,7 +93,7 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         uint32_t* big_list = (uint32_t*)(seg_list + max_seg);
         ZK_TRY(ws_get(g.msm_seg_out, max_seg * sizeof(XYZZ<C>)));
         HIP_TRY(hipMemsetAsync(q, 0, sizeof(MsmQueue), st));
-        const uint32_t ntasks = nwg * ((sh.rb + 63) / 64);
+        const uint32_t ntasks = (nwg * ((sh.rb + 63) / 64) * 64 + MSM_BATCH - 1) / MSM_BATCH;  // batches in the queue
         unsigned waves_per_simd = 4;
         if (const char* e = getenv("ZK_MSM_WAVES")) {
             int v = atoi(e);
@@ -106,7 +107,7 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         const unsigned big_grid = max_seg < 4096 ? (unsigned)max_seg : 4096u;
         ZK_LAUNCH((msm_accumulate_big_kernel<C>), big_grid, 64, 0, st, (const Affine<C>*)be.dev, (const uint32_t*)g.msm_sorted.p,
                   (const MsmQueue*)q, (const MsmSeg*)seg_list, (XYZZ<C>*)g.msm_seg_out.p);
-        ZK_LAUNCH((msm_combine_big_kernel<C>), big_grid < 64 ? big_grid : 64u, 256, 0, st, (const MsmQueue*)q, (const uint32_t*)big_list,
+        ZK_LAUNCH((msm_combine_big_kernel<C>), big_grid < 64 ? big_grid : 64u, tree_lanes<C>(), 0, st, (const MsmQueue*)q, (const uint32_t*)big_list,
                   (const uint32_t*)counts, (const XYZZ<C>*)g.msm_seg_out.p, (XYZZ<C>*)g.msm_buckets.p);
         HIP_TRY(hipEventRecord(g.ev[4], st));
         ZK_LAUNCH((msm_reduce_kernel<C>), (nslices + 63) / 64, 64, 0, st, (const XYZZ<C>*)g.msm_buckets.p,
@@ -117,9 +118,9 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         uint32_t per = spw;
         while (per > 8) {
             const uint32_t E = per >= 1024 ? 4 : 1;
-            const uint32_t chunk = 256 * E;
+            const uint32_t chunk = tree_lanes<C>() * E;
             const uint32_t per_out = (per + chunk - 1) / chunk;
-            ZK_LAUNCH((msm_sum_kernel<C>), (unsigned)sh.nw * per_out, 256, 0, st, (const XYZZ<C>*)cur, nxt, per, per_out, E);
+            ZK_LAUNCH((msm_sum_kernel<C>), (unsigned)sh.nw * per_out, tree_lanes<C>(), 0, st, (const XYZZ<C>*)cur, nxt, per, per_out, E);
             per = per_out;
             XYZZ<C>* t = cur;
             cur = nxt;
@@ -147,7 +148,7 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         g.prof.total_ms += g.prof.host_tail_ms;
     }
     xyzz_to_jacobian(result, total);
-    memcpy(out_jac, &result, 3 * sizeof(uint32_t) * Fq::N);
+    memcpy(out_jac, &result, 3 * sizeof(uint32_t) * coord_words<C>());
     return ZK_OK;
 }
 

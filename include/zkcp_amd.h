@@ -19,7 +19,8 @@
  * INTEGRATION.md shows the Rust-side stubs.  Conventions:
  *   - plain pointers and sizes, little-endian u64 limbs (== little-endian u32 words);
  *   - field elements in Montgomery form, R = 2^256 (2^384 for BLS12-381 Fq), unless stated;
- *   - affine points are (x, y); the point at infinity is encoded as x = y = 0;
+ *   - affine points are (x, y); the point at infinity is encoded as x = y = 0; on the G2 curves a
+ *     coordinate is an Fq2 element stored c0 then c1 (ark-ff 0.3 Fp2 { c0, c1 });
  *   - results are Jacobian (X, Y, Z), identity has Z = 0 -- the in-memory form of ark-ec 0.3
  *     `GroupProjective` and pasta_curves 0.4 `Ep`/`Eq`;
  *   - every function returns 0 on success or a negative zk_status; nothing throws or aborts;
@@ -42,7 +43,9 @@ typedef enum {
     ZK_PALLAS = 0,       /* y^2 = x^3 + 5 over Fp, scalars in Fq   (pasta_curves 0.4 `pallas`) */
     ZK_VESTA = 1,        /* y^2 = x^3 + 5 over Fq, scalars in Fp   (pasta_curves 0.4 `vesta`; halo2 commitments over pallas::Base) */
     ZK_BN254_G1 = 2,     /* ark-bn254 0.3 G1 */
-    ZK_BLS12_381_G1 = 3  /* ark-bls12-381 0.3 G1 -- the curve the reference proves on (lib/src/lib.rs:21-24) */
+    ZK_BLS12_381_G1 = 3, /* ark-bls12-381 0.3 G1 -- the curve the reference proves on (lib/src/lib.rs:21-24) */
+    ZK_BN254_G2 = 4,     /* ark-bn254 0.3 G2: y^2 = x^3 + 3/(9+u) over Fq2 = Fq[u]/(u^2+1); a coordinate is (c0, c1) */
+    ZK_BLS12_381_G2 = 5  /* ark-bls12-381 0.3 G2: y^2 = x^3 + 4(1+u) over Fq2 -- Groth16's b_g2_query MSM */
 } zk_curve_t;
 
 typedef enum {
@@ -85,7 +88,7 @@ int zk_backend_info(char *buf, uint64_t buflen); /* e.g. "hip gfx950 AMD Instinc
 
 /* ---- sizes ---- */
 int zk_field_limbs64(zk_field_t f);            /* u64 limbs per scalar-field element (4) */
-int zk_curve_base_limbs64(zk_curve_t c);       /* u64 limbs per base-field element (4, or 6 for BLS12-381) */
+int zk_curve_base_limbs64(zk_curve_t c);       /* u64 limbs per point coordinate: Fq 4 (6 for BLS12-381); Fq2 on the G2 curves 8 (12) */
 int zk_curve_scalar_field(zk_curve_t c);       /* zk_field_t of the curve's scalars */
 int zk_msm_window_bits(zk_curve_t c, uint64_t n, int requested);            /* c actually used */
 int zk_msm_window_count(zk_curve_t c, uint64_t n, int window_bits);         /* ceil((bits+1)/c) */

@@ -35,7 +35,24 @@ CURVES = {
                  0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
                  0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1),
 }
-CURVE_IDS = ["Pallas", "Vesta", "Bn254G1", "Bls381G1"]
+# G2 twists: coordinates in Fq2 = Fq[u]/(u^2+1), written as (c0, c1) tuples
+CURVES["Bn254G2"] = ("Bn254Fq", "Bn254Fr",
+                     (19485874751759354771024239261021720505790618469301721065564631296452457478373,
+                      266929791119991161246907387137283842545076965332900288569378510910307636690),
+                     (10857046999023057135944570762232829481370756359578518086990519993285655852781,
+                      11559732032986387107991004021392285783925812861821192530917403151452391805634),
+                     (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+                      4082367875863433681332203403145435568316851327593401208105741076214120093531))
+CURVES["Bls381G2"] = ("Bls381Fq", "Bls381Fr", (4, 4),
+                      (0x024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8,
+                       0x13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e),
+                      (0x0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801,
+                       0x0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be))
+CURVE_IDS = ["Pallas", "Vesta", "Bn254G1", "Bls381G1", "Bn254G2", "Bls381G2"]
+
+
+def is_g2(curve):
+    return isinstance(CURVES[curve][2], tuple)
 
 MASK64 = (1 << 64) - 1
 
@@ -93,9 +110,44 @@ def unmont(field, x):
     return x * pow(1 << (64 * nl), -1, p) % p
 
 
+# ------------------------------------------------------------------ coordinate-field arithmetic: ints (Fq) or (c0, c1) tuples (Fq2)
+class K:
+    """Arithmetic in the coordinate field of `curve`."""
+
+    def __init__(self, curve):
+        self.p = FIELDS[CURVES[curve][0]][0]
+        self.ext = 2 if is_g2(curve) else 1
+
+    def add(self, a, b):
+        return (a + b) % self.p if self.ext == 1 else ((a[0] + b[0]) % self.p, (a[1] + b[1]) % self.p)
+
+    def sub(self, a, b):
+        return (a - b) % self.p if self.ext == 1 else ((a[0] - b[0]) % self.p, (a[1] - b[1]) % self.p)
+
+    def mul(self, a, b):
+        if self.ext == 1:
+            return a * b % self.p
+        return ((a[0] * b[0] - a[1] * b[1]) % self.p, (a[0] * b[1] + a[1] * b[0]) % self.p)
+
+    def small(self, k, a):
+        return k * a % self.p if self.ext == 1 else (k * a[0] % self.p, k * a[1] % self.p)
+
+    def inv(self, a):
+        if self.ext == 1:
+            return pow(a, -1, self.p)
+        n = pow(a[0] * a[0] + a[1] * a[1], -1, self.p)
+        return (a[0] * n % self.p, -a[1] * n % self.p)
+
+    def zero(self, a):
+        return a == 0 if self.ext == 1 else a == (0, 0)
+
+    def neg(self, a):
+        return (-a) % self.p if self.ext == 1 else ((-a[0]) % self.p, (-a[1]) % self.p)
+
+
 # ------------------------------------------------------------------ affine curve arithmetic (None = infinity)
 def ec_add(curve, P, Q):
-    p = FIELDS[CURVES[curve][0]][0]
+    k = K(curve)
     if P is None:
         return Q
     if Q is None:
@@ -103,13 +155,17 @@ def ec_add(curve, P, Q):
     x1, y1 = P
     x2, y2 = Q
     if x1 == x2:
-        if (y1 + y2) % p == 0:
+        if k.zero(k.add(y1, y2)):
             return None
-        lam = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+        lam = k.mul(k.small(3, k.mul(x1, x1)), k.inv(k.small(2, y1)))
     else:
-        lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
-    x3 = (lam * lam - x1 - x2) % p
-    return x3, (lam * (x1 - x3) - y1) % p
+        lam = k.mul(k.sub(y2, y1), k.inv(k.sub(x2, x1)))
+    x3 = k.sub(k.sub(k.mul(lam, lam), x1), x2)
+    return x3, k.sub(k.mul(lam, k.sub(x1, x3)), y1)
+
+
+def ec_neg(curve, P):
+    return None if P is None else (P[0], K(curve).neg(P[1]))
 
 
 def ec_mul(curve, k, P):
@@ -125,9 +181,9 @@ def ec_mul(curve, k, P):
 def ec_on_curve(curve, P):
     if P is None:
         return True
-    bf, _, b, _, _ = CURVES[curve]
-    p = FIELDS[bf][0]
-    return (P[1] * P[1] - P[0] ** 3 - b) % p == 0
+    k = K(curve)
+    b = CURVES[curve][2]
+    return k.zero(k.sub(k.mul(P[1], P[1]), k.add(k.mul(k.mul(P[0], P[0]), P[0]), b)))
 
 
 def msm_naive(curve, scalars, points):
@@ -178,6 +234,10 @@ def hash_name(name):
     return h
 
 
+def coord_hex(c):
+    return hexs(c) if not isinstance(c, tuple) else [hexs(c[0]), hexs(c[1])]
+
+
 def gen_msm_vectors(seed=0x5EEDC0DE, sizes=(1, 2, 5, 33, 64)):
     out = {"seed": seed, "curves": {}}
     for cname in CURVE_IDS:
@@ -197,18 +257,18 @@ def gen_msm_vectors(seed=0x5EEDC0DE, sizes=(1, 2, 5, 33, 64)):
                 sc[0], sc[1], sc[2], sc[3] = 0, 1, r - 1, 0xFF
                 pts[4] = pts[3]
             if n >= 33:
-                pts[7] = (pts[6][0], (-pts[6][1]) % FIELDS[bf][0])   # P and -P
+                pts[7] = ec_neg(cname, pts[6])                       # P and -P
                 sc[7] = sc[6]                                        # cancels exactly
                 pts[9] = None                                        # identity base
             res = msm_naive(cname, sc, pts)
             cases.append({
                 "n": n,
                 "scalars": [hexs(s) for s in sc],
-                "points": [None if P is None else [hexs(P[0]), hexs(P[1])] for P in pts],
-                "result": None if res is None else [hexs(res[0]), hexs(res[1])],
+                "points": [None if P is None else [coord_hex(P[0]), coord_hex(P[1])] for P in pts],
+                "result": None if res is None else [coord_hex(res[0]), coord_hex(res[1])],
             })
-        out["curves"][cname] = {"base_field": bf, "scalar_field": sf, "b": b,
-                                "generator": [hexs(gx), hexs(gy)], "cases": cases}
+        out["curves"][cname] = {"base_field": bf, "scalar_field": sf, "b": b if not isinstance(b, tuple) else list(b),
+                                "generator": [coord_hex(gx), coord_hex(gy)], "cases": cases}
     return out
 
 

@@ -44,11 +44,6 @@ EXPORT int orc_curve_scalar_field(int c) { return ORC_CURVES[c].scalar_field; }
 EXPORT void orc_field_modulus(int f, uint64_t *out) { memcpy(out, ORC_FIELDS[f].p, 8 * field_nl(f)); }
 EXPORT void orc_field_root(int f, uint64_t *out) { memcpy(out, ORC_FIELDS[f].root_mont, 8 * field_nl(f)); }
 EXPORT void orc_field_generator(int f, uint64_t *out) { memcpy(out, ORC_FIELDS[f].gen_mont, 8 * field_nl(f)); }
-EXPORT void orc_curve_generator(int c, uint64_t *out) {
-    int nl = field_nl(ORC_CURVES[c].base_field);
-    memcpy(out, ORC_CURVES[c].gx_mont, 8 * nl);
-    memcpy(out + nl, ORC_CURVES[c].gy_mont, 8 * nl);
-}
 
 /* ---- field element ops: op 0 add, 1 sub, 2 mul, 3 inv(a), 4 to_mont(a), 5 from_mont(a), 6 neg(a) ---- */
 EXPORT void orc_fe_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *r) {
@@ -90,68 +85,73 @@ EXPORT void orc_fe_batch_convert(int field, int to_mont, const uint64_t *in, uin
     for (size_t i = 0; i < n; i++) orc_fe_op(field, to_mont ? 4 : 5, in + i * nl, NULL, out + i * nl);
 }
 
-/* ---- curve ops ---- */
-#define CURVE_DISPATCH(c, CALL4, CALL6)                                  \
+/* ---- curve ops: 4-way dispatch over (base-field limbs, coordinate extension degree) ---- */
+#define PASTE3_(a, b, c) a##b##c
+#define PASTE3(a, b, c) PASTE3_(a, b, c)
+#define CURVE_CALL(c, BODY)                                              \
     do {                                                                 \
-        if (field_nl(ORC_CURVES[c].base_field) == 4) { CALL4; } else { CALL6; } \
+        const int nl_ = field_nl(ORC_CURVES[c].base_field);              \
+        const int ext_ = ORC_CURVES[c].ext;                              \
+        if (ext_ == 1 && nl_ == 4) { BODY(_4, 4) }                       \
+        else if (ext_ == 1) { BODY(_6, 6) }                              \
+        else if (nl_ == 4) { BODY(_g2_4, 4) }                            \
+        else { BODY(_g2_6, 6) }                                          \
     } while (0)
+/* u64 limbs per coordinate */
+static int coord_nl(int c) { return field_nl(ORC_CURVES[c].base_field) * ORC_CURVES[c].ext; }
+EXPORT int orc_curve_coord_limbs(int c) { return coord_nl(c); }
+EXPORT void orc_curve_generator(int c, uint64_t *out) {
+    int nl = coord_nl(c);
+    memcpy(out, ORC_CURVES[c].gx_mont, 8 * nl);
+    memcpy(out + nl, ORC_CURVES[c].gy_mont, 8 * nl);
+}
 
 EXPORT int orc_on_curve(int c, const uint64_t *aff) {
     int ok = 0;
-    CURVE_DISPATCH(c, {
-        fctx_4 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        fe_4 b; memcpy(&b, ORC_CURVES[c].b_mont, 32);
-        ok = aff_on_curve_4(&f, &b, (const aff_4 *)aff);
-    }, {
-        fctx_6 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        fe_6 b; memcpy(&b, ORC_CURVES[c].b_mont, 48);
-        ok = aff_on_curve_6(&f, &b, (const aff_6 *)aff);
-    });
+#define BODY(SUF, NLV)                                                         \
+    PASTE3(fctx_, NLV, ) f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};          \
+    ok = aff_on_curve##SUF(&f, (const void *)ORC_CURVES[c].b_mont, (const aff##SUF *)aff);
+    CURVE_CALL(c, BODY);
+#undef BODY
     return ok;
 }
 /* out = [k]P, k canonical 4 x u64 */
 EXPORT void orc_scalar_mul(int c, const uint64_t *aff_in, const uint64_t *k, uint64_t *aff_out) {
-    CURVE_DISPATCH(c, {
-        fctx_4 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_4 r; jac_scalar_mul_4(&f, &r, (const aff_4 *)aff_in, k, 4);
-        jac_to_aff_4(&f, (aff_4 *)aff_out, &r);
-    }, {
-        fctx_6 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_6 r; jac_scalar_mul_6(&f, &r, (const aff_6 *)aff_in, k, 4);
-        jac_to_aff_6(&f, (aff_6 *)aff_out, &r);
-    });
+#define BODY(SUF, NLV)                                                         \
+    PASTE3(fctx_, NLV, ) f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};          \
+    jac##SUF r;                                                                \
+    jac_scalar_mul##SUF(&f, &r, (const aff##SUF *)aff_in, k, 4);               \
+    jac_to_aff##SUF(&f, (aff##SUF *)aff_out, &r);
+    CURVE_CALL(c, BODY);
+#undef BODY
 }
 /* out = A + B, all affine */
 EXPORT void orc_point_add(int c, const uint64_t *a, const uint64_t *b, uint64_t *aff_out) {
-    CURVE_DISPATCH(c, {
-        fctx_4 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_4 r; jac_set_inf_4(&f, &r);
-        jac_add_mixed_4(&f, &r, (const aff_4 *)a); jac_add_mixed_4(&f, &r, (const aff_4 *)b);
-        jac_to_aff_4(&f, (aff_4 *)aff_out, &r);
-    }, {
-        fctx_6 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_6 r; jac_set_inf_6(&f, &r);
-        jac_add_mixed_6(&f, &r, (const aff_6 *)a); jac_add_mixed_6(&f, &r, (const aff_6 *)b);
-        jac_to_aff_6(&f, (aff_6 *)aff_out, &r);
-    });
+#define BODY(SUF, NLV)                                                         \
+    PASTE3(fctx_, NLV, ) f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};          \
+    jac##SUF r;                                                                \
+    jac_set_inf##SUF(&f, &r);                                                  \
+    jac_add_mixed##SUF(&f, &r, (const aff##SUF *)a);                           \
+    jac_add_mixed##SUF(&f, &r, (const aff##SUF *)b);                           \
+    jac_to_aff##SUF(&f, (aff##SUF *)aff_out, &r);
+    CURVE_CALL(c, BODY);
+#undef BODY
 }
 /* Jacobian (X,Y,Z) -> affine */
 EXPORT void orc_jac_to_affine(int c, const uint64_t *jac, uint64_t *aff_out) {
-    CURVE_DISPATCH(c, {
-        fctx_4 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_to_aff_4(&f, (aff_4 *)aff_out, (const jac_4 *)jac);
-    }, {
-        fctx_6 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_to_aff_6(&f, (aff_6 *)aff_out, (const jac_6 *)jac);
-    });
+#define BODY(SUF, NLV)                                                         \
+    PASTE3(fctx_, NLV, ) f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};          \
+    jac_to_aff##SUF(&f, (aff##SUF *)aff_out, (const jac##SUF *)jac);
+    CURVE_CALL(c, BODY);
+#undef BODY
 }
 
 /* P_i = [k_i]G for n canonical scalars (threaded): the seeded base generator of SURVEY 8d */
 typedef struct { int c; const uint64_t *k; uint64_t *out; size_t lo, hi; } genjob;
 static void *gen_worker(void *arg) {
     genjob *j = (genjob *)arg;
-    int nl = field_nl(ORC_CURVES[j->c].base_field);
-    uint64_t g[12];
+    int nl = coord_nl(j->c);
+    uint64_t g[24];
     orc_curve_generator(j->c, g);
     for (size_t i = j->lo; i < j->hi; i++) orc_scalar_mul(j->c, g, j->k + 4 * i, j->out + 2 * nl * i);
     return NULL;
@@ -170,28 +170,24 @@ EXPORT void orc_fixed_base_mul(int c, const uint64_t *scalars, size_t n, int thr
 
 /* ---- MSM variants; all return the affine result ---- */
 EXPORT void orc_msm_naive(int c, const uint64_t *bases, const uint64_t *scalars_canonical, size_t n, uint64_t *aff_out) {
-    CURVE_DISPATCH(c, {
-        fctx_4 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_4 r; msm_naive_4(&f, &r, (const aff_4 *)bases, scalars_canonical, 4, n);
-        jac_to_aff_4(&f, (aff_4 *)aff_out, &r);
-    }, {
-        fctx_6 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_6 r; msm_naive_6(&f, &r, (const aff_6 *)bases, scalars_canonical, 4, n);
-        jac_to_aff_6(&f, (aff_6 *)aff_out, &r);
-    });
+#define BODY(SUF, NLV)                                                         \
+    PASTE3(fctx_, NLV, ) f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};          \
+    jac##SUF r;                                                                \
+    msm_naive##SUF(&f, &r, (const aff##SUF *)bases, scalars_canonical, 4, n);  \
+    jac_to_aff##SUF(&f, (aff##SUF *)aff_out, &r);
+    CURVE_CALL(c, BODY);
+#undef BODY
 }
 /* ark-ec 0.3 VariableBaseMSM::multi_scalar_mul(bases, scalars: canonical BigInt) */
 EXPORT void orc_msm_ark(int c, const uint64_t *bases, const uint64_t *scalars_canonical, size_t n, int threads, uint64_t *aff_out) {
     int bits = ORC_FIELDS[ORC_CURVES[c].scalar_field].nbits;
-    CURVE_DISPATCH(c, {
-        fctx_4 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_4 r; msm_ark_4(&f, &r, (const aff_4 *)bases, scalars_canonical, 4, n, bits, threads);
-        jac_to_aff_4(&f, (aff_4 *)aff_out, &r);
-    }, {
-        fctx_6 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_6 r; msm_ark_6(&f, &r, (const aff_6 *)bases, scalars_canonical, 4, n, bits, threads);
-        jac_to_aff_6(&f, (aff_6 *)aff_out, &r);
-    });
+#define BODY(SUF, NLV)                                                         \
+    PASTE3(fctx_, NLV, ) f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};          \
+    jac##SUF r;                                                                \
+    msm_ark##SUF(&f, &r, (const aff##SUF *)bases, scalars_canonical, 4, n, bits, threads); \
+    jac_to_aff##SUF(&f, (aff##SUF *)aff_out, &r);
+    CURVE_CALL(c, BODY);
+#undef BODY
 }
 EXPORT int orc_msm_ark_window_bits(size_t n) { return ark_c_4(n); }
 /* halo2_proofs 0.2 best_multiexp(coeffs: Montgomery scalars, bases) */
@@ -199,15 +195,13 @@ EXPORT void orc_msm_halo2(int c, const uint64_t *bases, const uint64_t *scalars_
     int sf = ORC_CURVES[c].scalar_field;
     uint8_t *repr = (uint8_t *)malloc(32 * n + 8);
     orc_fe_batch_convert(sf, 0, scalars_mont, (uint64_t *)repr, n); /* to_repr(): canonical LE bytes (x86 is LE) */
-    CURVE_DISPATCH(c, {
-        fctx_4 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_4 r; msm_halo2_4(&f, &r, (const aff_4 *)bases, repr, n, threads);
-        jac_to_aff_4(&f, (aff_4 *)aff_out, &r);
-    }, {
-        fctx_6 f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};
-        jac_6 r; msm_halo2_6(&f, &r, (const aff_6 *)bases, repr, n, threads);
-        jac_to_aff_6(&f, (aff_6 *)aff_out, &r);
-    });
+#define BODY(SUF, NLV)                                                         \
+    PASTE3(fctx_, NLV, ) f = {&ORC_FIELDS[ORC_CURVES[c].base_field]};          \
+    jac##SUF r;                                                                \
+    msm_halo2##SUF(&f, &r, (const aff##SUF *)bases, repr, n, threads);         \
+    jac_to_aff##SUF(&f, (aff##SUF *)aff_out, &r);
+    CURVE_CALL(c, BODY);
+#undef BODY
     free(repr);
 }
 

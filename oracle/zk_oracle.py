@@ -17,7 +17,7 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_DIR, "libzkoracle.so")
 
 FIELD_IDS = ["PallasFp", "PallasFq", "Bn254Fr", "Bls381Fr", "Bn254Fq", "Bls381Fq"]
-CURVE_IDS = ["Pallas", "Vesta", "Bn254G1", "Bls381G1"]
+CURVE_IDS = ["Pallas", "Vesta", "Bn254G1", "Bls381G1", "Bn254G2", "Bls381G2"]
 
 
 def build(force=False):
@@ -64,6 +64,11 @@ def curve_base_field(curve):
 
 def curve_scalar_field(curve):
     return lib().orc_curve_scalar_field(cid(curve))
+
+
+def coord_limbs(curve):
+    """u64 limbs per point coordinate: Fq limbs, times 2 on the G2 curves (Fq2 = c0 | c1)."""
+    return lib().orc_curve_coord_limbs(cid(curve))
 
 
 def int_to_limbs(x, nl):
@@ -129,7 +134,7 @@ def field_generator(field):
 
 
 def curve_generator(curve):
-    nl = field_nlimbs(curve_base_field(curve))
+    nl = coord_limbs(curve)
     out = np.zeros(2 * nl, dtype=np.uint64)
     lib().orc_curve_generator(cid(curve), _p(out))
     return out
@@ -164,7 +169,7 @@ def jac_to_affine(curve, jac):
 def fixed_base_mul(curve, scalars, threads=8):
     """P_i = [k_i]G (affine) for canonical scalars [n,4]."""
     scalars = _u64(scalars)
-    nl = field_nlimbs(curve_base_field(curve))
+    nl = coord_limbs(curve)
     out = np.zeros((scalars.shape[0], 2 * nl), dtype=np.uint64)
     lib().orc_fixed_base_mul(cid(curve), _p(scalars), ctypes.c_size_t(scalars.shape[0]), threads, _p(out))
     return out
@@ -173,7 +178,7 @@ def fixed_base_mul(curve, scalars, threads=8):
 def _msm(fn, curve, bases, scalars, *extra):
     bases, scalars = _u64(bases), _u64(scalars)
     assert bases.shape[0] == scalars.shape[0]
-    nl = field_nlimbs(curve_base_field(curve))
+    nl = coord_limbs(curve)
     out = np.zeros(2 * nl, dtype=np.uint64)
     fn(cid(curve), _p(bases), _p(scalars), ctypes.c_size_t(bases.shape[0]), *extra, _p(out))
     return out

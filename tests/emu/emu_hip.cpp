@@ -40,6 +40,17 @@ void syncthreads() {
     cur = &f->tc;
 }
 
+static int g_count_acc = 0;
+int syncthreads_count(int pred) {
+    g_count_acc += pred;
+    syncthreads();
+    const int r = g_count_acc;
+    syncthreads();
+    g_count_acc = 0;  // every fiber resets after the second barrier; all have read r by then
+    syncthreads();
+    return r;
+}
+
 void launch(unsigned grid, unsigned block, size_t shmem, const std::function<void()>& body) {
     if (grid == 0 || block == 0) return;
     g_block_dim = {block, 1, 1};

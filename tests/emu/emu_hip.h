@@ -27,6 +27,7 @@ extern Dim3 g_block_dim, g_grid_dim;
 extern char* g_dyn_smem;
 void launch(unsigned grid, unsigned block, size_t shmem, const std::function<void()>& body);
 void syncthreads();
+int syncthreads_count(int pred);
 }  // namespace emu
 
 #define threadIdx (emu::cur->tid)
@@ -34,6 +35,7 @@ void syncthreads();
 #define blockDim (emu::g_block_dim)
 #define gridDim (emu::g_grid_dim)
 #define __syncthreads() emu::syncthreads()
+#define __syncthreads_count(p) emu::syncthreads_count((p) ? 1 : 0)
 #define __global__
 #define __device__
 #define __host__

@@ -14,7 +14,32 @@ from oracle import zk_oracle as orc
 H = lambda s: int(s, 16)
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NTT_FIELDS = ["PallasFp", "PallasFq", "Bn254Fr", "Bls381Fr"]
-CURVES = ["Pallas", "Vesta", "Bn254G1", "Bls381G1"]
+CURVES = ["Pallas", "Vesta", "Bn254G1", "Bls381G1", "Bn254G2", "Bls381G2"]
+
+
+def coord_array(cname, c):
+    """golden coordinate (hex string, or [c0, c1] hex pair on G2) -> Montgomery u64 limbs (c0 | c1)"""
+    bf = pyref.CURVES[cname][0]
+    nl = pyref.FIELDS[bf][2]
+    parts = c if isinstance(c, list) else [c]
+    return np.concatenate([orc.int_to_limbs(pyref.mont(bf, H(x)), nl) for x in parts])
+
+
+def golden_msm_case(cname, case):
+    """-> (points [n, 2L], scalars [n,4], expected affine [2L]) as uint64 arrays"""
+    L = orc.coord_limbs(cname)
+    n = case["n"]
+    pts = np.zeros((n, 2 * L), dtype=np.uint64)
+    for i, P in enumerate(case["points"]):
+        if P is not None:
+            pts[i, :L] = coord_array(cname, P[0])
+            pts[i, L:] = coord_array(cname, P[1])
+    sc = orc.ints_to_array([H(x) for x in case["scalars"]], 4)
+    exp = np.zeros(2 * L, dtype=np.uint64)
+    if case["result"] is not None:
+        exp[:L] = coord_array(cname, case["result"][0])
+        exp[L:] = coord_array(cname, case["result"][1])
+    return pts, sc, exp
 
 
 def rand_field(name, n, seed):
@@ -117,20 +142,10 @@ def affine_of(zk, curve, jac):
 def check_msm_golden(zk):
     v = json.load(open(os.path.join(GOLD, "msm_vectors.json")))["curves"]
     for cname in CURVES:
-        bf, sf = pyref.CURVES[cname][0], pyref.CURVES[cname][1]
-        nl = pyref.FIELDS[bf][2]
+        sf = pyref.CURVES[cname][1]
         for case in v[cname]["cases"]:
             n = case["n"]
-            pts = np.zeros((n, 2 * nl), dtype=np.uint64)
-            for i, P in enumerate(case["points"]):
-                if P is not None:
-                    pts[i, :nl] = orc.int_to_limbs(pyref.mont(bf, H(P[0])), nl)
-                    pts[i, nl:] = orc.int_to_limbs(pyref.mont(bf, H(P[1])), nl)
-            sc = orc.ints_to_array([H(s) for s in case["scalars"]], 4)
-            exp = np.zeros(2 * nl, dtype=np.uint64)
-            if case["result"] is not None:
-                exp[:nl] = orc.int_to_limbs(pyref.mont(bf, H(case["result"][0])), nl)
-                exp[nl:] = orc.int_to_limbs(pyref.mont(bf, H(case["result"][1])), nl)
+            pts, sc, exp = golden_msm_case(cname, case)
             bases = zk.Bases(cname, pts)
             for wb in (0, 3, 7):
                 got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=wb))
@@ -178,7 +193,7 @@ def check_msm_window_sharding(zk, cname, n, window_bits, parts):
 
 
 def check_msm_edges(zk, cname):
-    nl = pyref.FIELDS[pyref.CURVES[cname][0]][2]
+    nl = orc.coord_limbs(cname)
     g = orc.curve_generator(cname)
     r = pyref.FIELDS[pyref.CURVES[cname][1]][0]
     # empty input -> identity (Z = 0)

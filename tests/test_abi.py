@@ -60,10 +60,12 @@ def test_host_helpers_need_no_gpu():
         g = zk.multiplicative_generator(name)
         assert (g == orc.field_generator(name)).all()
         assert (zk.field_inverse(name, g) == orc.fe_op(name, "inv", g)).all()
-    for cname in ("Pallas", "Vesta", "Bn254G1", "Bls381G1"):
+    for cname in ("Pallas", "Vesta", "Bn254G1", "Bls381G1", "Bn254G2", "Bls381G2"):
         g = orc.curve_generator(cname)
         nl = g.shape[0] // 2
-        one = orc.to_mont(orc.curve_base_field(cname), orc.ints_to_array([1], nl))[0]
+        bl = orc.field_nlimbs(orc.curve_base_field(cname))
+        one = np.zeros(nl, dtype=np.uint64)
+        one[:bl] = orc.to_mont(orc.curve_base_field(cname), orc.ints_to_array([1], bl))[0]   # (1, 0) on G2
         jac = np.concatenate([g, one])
         assert (zk.point_to_affine(cname, jac) == g).all()
         two = zk.point_add(cname, jac, jac)                      # doubling branch

@@ -84,6 +84,17 @@ __global__ void k_madd(XYZZ<C>* out, const Affine<C>* in, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// sustained shader clock under the mixed-add instruction stream: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime)
+template <class C>
+__global__ void k_madd_clock(XYZZ<C>* out, const Affine<C>* in, int iters, unsigned long long* stamps) {
+    XYZZ<C> acc; xyzz_set_inf(acc);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i++) { Affine<C> p = in[(threadIdx.x + i) & 63]; xyzz_add_mixed(acc, p); }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <class L>
 float time_ms(L&& launch, int reps = 5) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -111,7 +122,7 @@ template <class C> void bench_madd(const char* name, int blocks, int wpb) {
     using F = typename C::Fq;
     std::vector<Affine<C>> h(64);
     // points k*G by repeated host addition
-    Affine<C> g; for (int l = 0; l < F::N; l++) { g.x.v[l] = C::GX[l]; g.y.v[l] = C::GY[l]; }
+    Affine<C> g; curve_generator(g);
     XYZZ<C> acc; xyzz_set_inf(acc);
     for (int i = 0; i < 64; i++) { xyzz_add_mixed(acc, g); xyzz_to_affine(h[i], acc); }
     Affine<C>* din; XYZZ<C>* dout; CK(hipMalloc(&din, sizeof(Affine<C>) * 64)); CK(hipMalloc(&dout, sizeof(XYZZ<C>) * blocks * wpb * 64));
@@ -149,5 +160,22 @@ int main() {
         bench_field<Bls381Fq>("Bls381Fq", cus * 4, wpb);
     }
     for (int wpb : {1, 2, 4}) { bench_madd<Vesta>("Vesta", cus * 4, wpb); bench_madd<Bls381G1>("Bls381G1", cus * 4, wpb); }
+    {   // sustained clock: 4 waves/SIMD of mixed adds for tens of milliseconds
+        using C = Vesta; using F = C::Fq;
+        std::vector<Affine<C>> h(64);
+        Affine<C> g; curve_generator(g);
+        XYZZ<C> acc; xyzz_set_inf(acc);
+        for (int i = 0; i < 64; i++) { xyzz_add_mixed(acc, g); xyzz_to_affine(h[i], acc); }
+        const int blocks = cus * 16;
+        Affine<C>* din; XYZZ<C>* dout; unsigned long long* st;
+        CK(hipMalloc(&din, sizeof(Affine<C>) * 64)); CK(hipMalloc(&dout, sizeof(XYZZ<C>) * blocks * 64)); CK(hipMalloc(&st, 16 * blocks));
+        CK(hipMemcpy(din, h.data(), sizeof(Affine<C>) * 64, hipMemcpyHostToDevice));
+        for (int iters : {64, 256, 2048, 8192}) {
+            float t = time_ms([&] { hipLaunchKernelGGL((k_madd_clock<C>), dim3(blocks), dim3(64), 0, 0, dout, din, iters, st); }, 3);
+            std::vector<unsigned long long> hs(2 * blocks); CK(hipMemcpy(hs.data(), st, 16 * blocks, hipMemcpyDeviceToHost));
+            double cyc = 0, tick = 0; for (int b = 0; b < blocks; b++) { cyc += hs[2 * b]; tick += hs[2 * b + 1]; }
+            printf("sustained: iters=%5d  %.2f ms  %.2f Gadd/s  shader clock %.0f MHz\n", iters, t, (double)blocks * 64 * iters / t / 1e6, cyc / tick * 100.0);
+        }
+    }
     return 0;
 }

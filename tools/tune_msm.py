@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Sweep the MSM launch knobs (env: ZK_MSM_C, ZK_MSM_SLICE, ZK_MSM_WAVES, ZK_MSM_BIG) on one GPU; prints phase times."""
+import itertools, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import contangle_zkcp_amd as zk
+import parity_suite as ps
+
+curve = sys.argv[1] if len(sys.argv) > 1 else "Vesta"
+logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+n = 1 << logn
+zk.load(); zk.init(0)
+nl = zk.base_limbs(curve)
+ks = ps.scalars_for(curve, n, 0x5EED)
+d_pts = torch.empty((n, 2 * nl), dtype=torch.int64, device="cuda")
+zk.fixed_base_mul_device(curve, torch.from_numpy(ks.view(np.int64)).cuda(), d_pts, n)
+torch.cuda.synchronize()
+bases = zk.Bases(curve, device_tensor=d_pts, n=n)
+d_sc = torch.from_numpy(ps.scalars_for(curve, n, 0xC0DE).view(np.int64)).cuda()
+ref = None
+grid = {"ZK_MSM_C": ["16", "15", "14", "13"], "ZK_MSM_SLICE": ["2", "4", "8", "16"], "ZK_MSM_WAVES": ["2", "4", "8"]}
+base = {"ZK_MSM_C": "16", "ZK_MSM_SLICE": "8", "ZK_MSM_WAVES": "4"}
+configs = [dict(base)]
+for k, vals in grid.items():
+    for v in vals:
+        c = dict(base); c[k] = v
+        if c not in configs: configs.append(c)
+for c in configs:
+    os.environ.update(c)
+    for _ in range(2): out = zk.msm(bases, d_sc)
+    acc = {}
+    R = 5
+    for _ in range(R):
+        out = zk.msm(bases, d_sc)
+        p = zk.msm_last_profile()
+        for k, v in p.items(): acc[k] = acc.get(k, 0) + v / R
+    aff = zk.point_to_affine(curve, out)
+    if ref is None: ref = aff
+    ok = bool((aff == ref).all())
+    print(c, "ok" if ok else "MISMATCH", {k: round(v, 3) for k, v in acc.items() if k.endswith("_ms")}, flush=True)
