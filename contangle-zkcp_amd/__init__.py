@@ -30,7 +30,7 @@ EXPORTS = [
     "zk_curve_scalar_field", "zk_msm_window_bits", "zk_msm_window_count", "zk_bases_upload", "zk_bases_adopt_device",
     "zk_bases_free", "zk_msm", "zk_msm_device", "zk_msm_last_profile", "zk_ntt", "zk_ntt_device", "zk_coset_mul",
     "zk_coset_mul_device", "zk_field_root_of_unity", "zk_field_multiplicative_generator", "zk_field_inverse",
-    "zk_point_add", "zk_point_to_affine", "zk_fixed_base_mul_device",
+    "zk_point_add", "zk_point_to_affine", "zk_fixed_base_mul_device", "zk_vec_op_device", "zk_groth16_witness_map_device",
 ]
 
 
@@ -82,6 +82,8 @@ def load(path=None):
     lib.zk_point_add.argtypes = [i32, vp, vp, vp]
     lib.zk_point_to_affine.argtypes = [i32, vp, vp]
     lib.zk_fixed_base_mul_device.argtypes = [i32, vp, u64, vp, vp]
+    lib.zk_vec_op_device.argtypes = [i32, i32, vp, vp, vp, u64, vp, vp]
+    lib.zk_groth16_witness_map_device.argtypes = [i32, vp, vp, vp, ctypes.c_uint32, vp]
     lib.zk_msm_window_bits.argtypes = [i32, u64, i32]
     lib.zk_msm_window_count.argtypes = [i32, u64, i32]
     lib.zk_backend_info.argtypes = [ctypes.c_char_p, u64]
@@ -269,6 +271,28 @@ def coset_mul(field, a, g, stream=0):
         return buf
     log_n = int(a.shape[0]).bit_length() - 1
     _check(lib.zk_coset_mul_device(field_id(field), _ptr(a), log_n, _ptr(gm), ctypes.c_void_p(stream)), "zk_coset_mul_device")
+    return a
+
+
+VEC_OPS = {"mul": 0, "sub": 1, "add": 2, "scale": 3, "into_repr": 4, "from_repr": 5, "qap": 6}
+
+
+def vec_op(field, op, a, b=None, c=None, scalar=None, stream=0):
+    """Pointwise kernels on device buffers (torch tensors, or numpy arrays under the test emulator)."""
+    n = int(a.shape[0])
+    sp = _ptr(_np64(scalar)) if scalar is not None else None
+    _check(load().zk_vec_op_device(field_id(field), VEC_OPS[op], _ptr(a), _ptr(b) if b is not None else None,
+                                   _ptr(c) if c is not None else None, n, sp, ctypes.c_void_p(stream)), "zk_vec_op_device")
+    return a
+
+
+def groth16_witness_map(field, a, b, c, stream=0):
+    """ark-groth16 0.3 R1CStoQAP::witness_map from the evaluation vectors a, b, c (device buffers); h lands in `a`."""
+    m = int(a.shape[0])
+    log_m = m.bit_length() - 1
+    assert m == 1 << log_m and int(b.shape[0]) == m and int(c.shape[0]) == m
+    _check(load().zk_groth16_witness_map_device(field_id(field), _ptr(a), _ptr(b), _ptr(c), log_m, ctypes.c_void_p(stream)),
+           "zk_groth16_witness_map_device")
     return a
 
 

@@ -20,12 +20,21 @@ FIELDS = ["PallasFp", "PallasFq", "Bn254Fr", "Bls381Fr"]
 UNITS = [("zk_api.cc", None, "api")] + \
         [("zk_msm_inst.cc", "ZK_CURVE=" + c, "msm_" + c) for c in CURVES] + \
         [("zk_ntt_inst.cc", "ZK_FIELD=" + f, "ntt_" + f) for f in FIELDS]
-HEADERS = ["zk_params.h", "zk_field.h", "zk_curve.h", "zk_kernels.h", "zk_rt.h", "zk_internal.h", "zk_msm.inl", "zk_ntt.inl"]
+COMMON = ["zk_params.h", "zk_mul_asm.h", "zk_field.h", "zk_curve.h", "zk_rt.h", "zk_internal.h"]
+PER_SOURCE = {   # headers only this kind of unit includes: an NTT edit does not rebuild the (slow) curve units
+    "zk_api.cc": [],
+    "zk_msm_inst.cc": ["zk_msm.inl", "zk_msm_kernels.h", "zk_host64.h"],
+    "zk_ntt_inst.cc": ["zk_ntt.inl", "zk_ntt_kernels.h"],
+}
 
 
-def _deps():
-    files = [os.path.join(CSRC, f) for f in HEADERS + sorted({u[0] for u in UNITS})]
-    return files + [os.path.join(ROOT, "include", "zkcp_amd.h")]
+def _deps(src=None):
+    names = set(COMMON)
+    for k, v in PER_SOURCE.items():
+        if src is None or k == src:
+            names.update(v)
+            names.add(k)
+    return [os.path.join(CSRC, f) for f in sorted(names)] + [os.path.join(ROOT, "include", "zkcp_amd.h")]
 
 
 def _newer(target, deps):
@@ -52,13 +61,13 @@ def _run(cmd, verbose):
     return r.stdout
 
 
-def _compile_all(base_cmd, objdir, deps, verbose, jobs):
+def _compile_all(base_cmd, objdir, extra_deps, verbose, jobs):
     os.makedirs(objdir, exist_ok=True)
     objs, todo = [], []
     for src, define, tag in UNITS:
         obj = os.path.join(objdir, tag + ".o")
         objs.append(obj)
-        if _newer(obj, deps):
+        if _newer(obj, _deps(src) + extra_deps):
             cmd = base_cmd + (["-D" + define] if define else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
             todo.append(cmd)
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
@@ -76,7 +85,7 @@ def build_hip(force=False, verbose=False, jobs=None):
         shutil.rmtree(objdir, ignore_errors=True)
     base = [hipcc_path(), "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
             "-fno-gpu-rdc", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    objs = _compile_all(base, objdir, deps, verbose, jobs)
+    objs = _compile_all(base, objdir, [], verbose, jobs)
     _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB + ".tmp"] + objs, verbose)
     os.replace(LIB + ".tmp", LIB)
     return LIB
@@ -96,7 +105,7 @@ def build_emu(force=False, verbose=False, sanitize=False, jobs=None):
             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if sanitize:
         base += ["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-g"]
-    objs = _compile_all(base, objdir, deps, verbose, jobs)
+    objs = _compile_all(base, objdir, [os.path.join(EMU_DIR, "emu_hip.h")], verbose, jobs)
     link = ["g++", "-shared", "-fPIC"] + (["-fsanitize=undefined"] if sanitize else []) + \
            ["-I" + EMU_DIR, "-O2", "-std=c++17", os.path.join(EMU_DIR, "emu_hip.cpp")] + objs + ["-o", out + ".tmp"]
     _run(link, verbose)

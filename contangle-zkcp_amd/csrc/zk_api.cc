@@ -260,6 +260,28 @@ API int zk_coset_mul(zk_field_t f, void* a_host, uint32_t log_n, const void* gm)
     return ZK_OK;
 }
 
+API int zk_vec_op_device(zk_field_t f, int op, void* a, const void* b, const void* c, uint64_t n, const void* scalar, void* stream) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    ZK_TRY(require_init());
+    if (op < 0 || op > 6 || (n && (!a || !aligned16(a)))) return ZK_ERR_INVALID_ARG;
+    const bool needs_b = op == 0 || op == 1 || op == 2 || op == 6, needs_c = op == 6, needs_s = op == 3 || op == 6;
+    if (n && ((needs_b && (!b || !aligned16(b))) || (needs_c && (!c || !aligned16(c))) || (needs_s && !scalar))) return ZK_ERR_INVALID_ARG;
+    FIELD_SWITCH(f, {
+        Fe<F> s;
+        fe_one(s);
+        if (needs_s) host_load(s, scalar);
+        return vec_op_run<F>((Fe<F>*)a, (const Fe<F>*)b, (const Fe<F>*)c, n, op, s, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_groth16_witness_map_device(zk_field_t f, void* a, void* b, void* c, uint32_t log_m, void* stream) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    ZK_TRY(require_init());
+    if (!a || !b || !c || !aligned16(a) || !aligned16(b) || !aligned16(c)) return ZK_ERR_INVALID_ARG;
+    FIELD_SWITCH(f, return witness_map_run<F>((int)f, (Fe<F>*)a, (Fe<F>*)b, (Fe<F>*)c, log_m, (hipStream_t)stream));
+    return ZK_ERR_INVALID_ARG;
+}
+
 API int zk_field_root_of_unity(zk_field_t f, uint32_t log_n, void* out) {
     if (!out) return ZK_ERR_INVALID_ARG;
     FIELD_SWITCH(f, {

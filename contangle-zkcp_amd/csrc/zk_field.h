@@ -122,17 +122,9 @@ ZK_HD void fe_dbl(Fe<P>& r, const Fe<P>& a) {
 // bit clear, so the running value stays below 2p < 2^(32N) and the (N+2)-th word of
 // textbook CIOS is never needed.
 template <class P>
-ZK_HD void fe_mul(Fe<P>& r, const Fe<P>& a, const Fe<P>& b) {
+ZK_HD void fe_mul_portable(Fe<P>& r, const Fe<P>& a, const Fe<P>& b) {
     constexpr int N = P::N;
     uint32_t t[N];
-#if defined(__HIP_DEVICE_COMPILE__)
-    // gfx950: hand-scheduled product scanning, 2 VALU instructions per partial product (zk_mul_asm.h)
-    fe_mul_asm<P>(t, a.v, b.v);
-    fe_reduce_once<P>(t);
-    ZK_UNROLL
-    for (int i = 0; i < N; i++) r.v[i] = t[i];
-    return;
-#endif
     ZK_UNROLL
     for (int i = 0; i < N; i++) t[i] = 0;
     ZK_UNROLL
@@ -160,6 +152,20 @@ ZK_HD void fe_mul(Fe<P>& r, const Fe<P>& a, const Fe<P>& b) {
     fe_reduce_once<P>(t);
     ZK_UNROLL
     for (int i = 0; i < N; i++) r.v[i] = t[i];
+}
+
+template <class P>
+ZK_HD void fe_mul(Fe<P>& r, const Fe<P>& a, const Fe<P>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // gfx950: hand-scheduled product scanning, 2 VALU instructions per partial product (zk_mul_asm.h)
+    uint32_t t[P::N];
+    fe_mul_asm<P>(t, a.v, b.v);
+    fe_reduce_once<P>(t);
+    ZK_UNROLL
+    for (int i = 0; i < P::N; i++) r.v[i] = t[i];
+#else
+    fe_mul_portable(r, a, b);
+#endif
 }
 
 template <class P>
@@ -224,6 +230,23 @@ template <class P>
 struct Fe2 {
     Fe<P> c0, c1;
 };
+// Base-field product as a real call (operands and result by value, i.e. in VGPRs): an Fq2 point addition
+// holds 30+ base multiplications; inlining every one of them makes the G2 kernels enormous (the BLS12-381
+// G2 code object took ten minutes to compile and spilled) for no gain -- the multiply is ~600 instructions.
+#if defined(__HIPCC__)
+#define ZK_HD_CALL __host__ __device__ __attribute__((noinline))
+#else
+#define ZK_HD_CALL __attribute__((noinline))
+#endif
+template <class P>
+ZK_HD_CALL Fe<P> fe_mul_call(Fe<P> a, Fe<P> b) {
+    Fe<P> r;
+    if (P::N > 8)
+        fe_mul_portable(r, a, b);   // 12-limb operands arrive through the stack: keep this callee free of inline asm
+    else
+        fe_mul(r, a, b);
+    return r;
+}
 template <class P>
 ZK_HD void fe_zero(Fe2<P>& r) {
     fe_zero(r.c0);
@@ -265,12 +288,12 @@ ZK_HD void fe_dbl(Fe2<P>& r, const Fe2<P>& a) {
 // Karatsuba: 3 base multiplications
 template <class P>
 ZK_HD void fe_mul(Fe2<P>& r, const Fe2<P>& a, const Fe2<P>& b) {
-    Fe<P> v0, v1, s, t;
-    fe_mul(v0, a.c0, b.c0);
-    fe_mul(v1, a.c1, b.c1);
+    Fe<P> s, t;
+    const Fe<P> v0 = fe_mul_call(a.c0, b.c0);
+    const Fe<P> v1 = fe_mul_call(a.c1, b.c1);
     fe_add(s, a.c0, a.c1);
     fe_add(t, b.c0, b.c1);
-    fe_mul(s, s, t);
+    s = fe_mul_call(s, t);
     fe_sub(s, s, v0);
     fe_sub(r.c1, s, v1);
     fe_sub(r.c0, v0, v1);
@@ -278,11 +301,11 @@ ZK_HD void fe_mul(Fe2<P>& r, const Fe2<P>& a, const Fe2<P>& b) {
 // (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u: 2 base multiplications
 template <class P>
 ZK_HD void fe_sqr(Fe2<P>& r, const Fe2<P>& a) {
-    Fe<P> s, d, m;
+    Fe<P> s, d;
     fe_add(s, a.c0, a.c1);
     fe_sub(d, a.c0, a.c1);
-    fe_mul(m, a.c0, a.c1);
-    fe_mul(r.c0, s, d);
+    const Fe<P> m = fe_mul_call(a.c0, a.c1);
+    r.c0 = fe_mul_call(s, d);
     fe_dbl(r.c1, m);
 }
 // 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2)

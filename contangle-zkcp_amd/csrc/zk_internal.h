@@ -14,7 +14,8 @@
 #include <mutex>
 #include <vector>
 
-#include "zk_kernels.h"
+#include "zk_rt.h"
+#include "zk_curve.h"
 
 namespace zk {
 
@@ -131,6 +132,10 @@ template <class F>
 int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st);
 template <class F>
 int coset_run(Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st);
+template <class F>
+int vec_op_run(Fe<F>* a, const Fe<F>* b, const Fe<F>* c, uint64_t n, int op, const Fe<F>& s, hipStream_t st);
+template <class F>
+int witness_map_run(int field, Fe<F>* a, Fe<F>* b, Fe<F>* c, uint32_t logm, hipStream_t st);
 template <class C>
 int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
             void* out_jac, hipStream_t st);

@@ -1,6 +1,8 @@
 // MSM launch sequence and host tail.  Included by zk_msm_inst.cc, once per curve.
 #pragma once
 #include "zk_internal.h"
+#include "zk_host64.h"
+#include "zk_msm_kernels.h"
 namespace zk {
 // ------------------------------------------------------------------ MSM
 inline double now_ms() {
@@ -132,12 +134,18 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         HIP_TRY(hipMemcpyAsync(host.data(), cur, host.size() * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const double t0 = now_ms();
-        // Horner over this call's windows, high to low, then the shift by 2^(c*w0)
+        // Horner over this call's windows, high to low, then the shift by 2^(c*w0) -- on 64-bit host limbs
+        HostXYZZ<C> htotal, hp;
+        to_host<C>(htotal, total);
         for (int w = sh.nw - 1; w >= 0; w--) {
-            for (int k = 0; k < c; k++) xyzz_dbl(total);
-            for (uint32_t i = 0; i < per; i++) xyzz_add(total, host[(size_t)w * per + i]);
+            for (int k = 0; k < c; k++) xyzz_dbl(htotal);
+            for (uint32_t i = 0; i < per; i++) {
+                to_host<C>(hp, host[(size_t)w * per + i]);
+                xyzz_add(htotal, hp);
+            }
         }
-        for (int k = 0; k < c * w0; k++) xyzz_dbl(total);
+        for (int k = 0; k < c * w0; k++) xyzz_dbl(htotal);
+        from_host<C>(total, htotal);
         g.prof.host_tail_ms = (float)(now_ms() - t0);
         hipEventElapsedTime(&g.prof.digits_ms, g.ev[0], g.ev[1]);
         hipEventElapsedTime(&g.prof.hist_ms, g.ev[1], g.ev[2]);

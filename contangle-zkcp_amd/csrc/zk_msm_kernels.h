@@ -1,0 +1,475 @@
+// HIP kernels for the MSM / NTT hot path (gfx950).  Replaces, behind the C ABI of
+// include/zkcp_amd.h, the upstream CPU routines the reference reaches through
+// `Groth16::<Bls12_381>::prove` (lib/src/zk/verifiable_encryption.rs:92, encryption.rs:76,
+// sample_entries.rs:86, property.rs:133):
+//   ark-ec 0.3   msm/variable_base.rs   VariableBaseMSM::multi_scalar_mul      
+//   ark-poly 0.3 domain/radix2/fft.rs   Radix2EvaluationDomain::*fft_in_place  
+//   halo2_proofs 0.2 arithmetic.rs      best_multiexp / best_fft               
+// Design notes (data layout, roofline per kernel) are in DESIGN.md.
+// This header: the MSM kernels (curves); the NTT / pointwise kernels are in zk_ntt_kernels.h.
+#pragma once
+#include "zk_rt.h"
+// (zk_rt.h first: it brings in the HIP runtime or the test emulator)
+#include "zk_curve.h"
+
+namespace zk {
+
+// ------------------------------------------------------------------------------------------
+// MSM: signed-digit Pippenger.
+//   1. msm_digits_kernel     scalar -> W signed c-bit digits, stored as u16 codes, window-major
+//   2. msm_hist_kernel       one workgroup per (window, bucket range): LDS histogram of its range
+//   3. msm_scatter_kernel    same grid: LDS scan -> bucket offsets, size-ordered bucket list, and the
+//                            counting-sort scatter of (point index | sign) through LDS cursors
+//   4. msm_accumulate_kernel one lane per bucket (largest first), XYZZ mixed adds over its slice
+//   5. msm_reduce_kernel     sum_b b*B_b by slices: X_t = W_t + [t*L] S_t
+//   6. msm_sum_kernel        per-window tree sums of X_t
+//   host: <= a few points per window, Horner over windows (c doublings each).
+// Digits are in [-(2^(c-1)-1), 2^(c-1)]; bucket index b-1 (b = |digit| in 1..2^(c-1)) holds the sum of
+// (+-)P_i.  No global atomics: every counter lives in the LDS of the workgroup that owns its bucket
+// range, and each workgroup scatters into its own contiguous slice of the sorted array (so the
+// 4-byte scattered stores combine in that XCD's L2 before they reach HBM).
+// ------------------------------------------------------------------------------------------
+struct MsmShape {
+    uint32_t n;
+    uint32_t n_pad;   // digit row stride (u16 elements), multiple of 8 so rows are 16-byte aligned
+    int c;            // window bits (<= 16)
+    int w0, nw;       // this call accumulates windows [w0, w0 + nw) of the scalar (window-range sharding)
+    uint32_t nbk;     // buckets per window = 2^(c-1)
+    uint32_t rb;      // buckets per workgroup range
+    uint32_t nranges; // ranges per window = nbk / rb
+    int mont;         // scalars arrive in Montgomery form (halo2) rather than canonical (ark BigInt)
+    uint32_t big_thresh;  // buckets longer than this take the cooperative path
+    uint32_t idx_mask;    // 0x7fffffff; narrowed only by the ZK_MSM_DEBUG_MASK profiling experiment (wrong results!)
+};
+
+template <int N>
+__device__ __forceinline__ uint32_t word_at(const uint32_t (&s)[N], int idx) {
+    uint32_t v = 0;
+    ZK_UNROLL
+    for (int k = 0; k < N; k++) v = (idx == k) ? s[k] : v;
+    return v;
+}
+template <int N>
+__device__ __forceinline__ uint32_t bits_at(const uint32_t (&s)[N], int start, int c) {
+    const int idx = start >> 5, off = start & 31;
+    uint64_t v = word_at<N>(s, idx);
+    v |= (uint64_t)word_at<N>(s, idx + 1) << 32;  // idx+1 == N selects 0
+    return (uint32_t)(v >> off) & ((1u << c) - 1);
+}
+
+// u16 digit code: two's complement of the signed digit; positive magnitudes reach 2^15 (0x8000),
+// negative ones only 2^15 - 1, so the code is unambiguous:  neg <=> code > 0x8000.
+__device__ __forceinline__ uint32_t digit_mag(uint32_t code, bool& neg) {
+    neg = code > 0x8000u;
+    return neg ? 0x10000u - code : code;
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) msm_digits_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh,
+                                                         uint16_t* __restrict__ digits) {
+    using Fr = typename C::Fr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sh.n_pad) return;
+    if (i >= sh.n) {  // row padding: zero digits
+        for (int w = 0; w < sh.nw; w++) digits[(uint64_t)w * sh.n_pad + i] = 0;
+        return;
+    }
+    Fe<Fr> x = scalars[i];
+    if (sh.mont) fe_from_mont(x, x);
+    uint32_t carry = 0;
+    for (int w = 0; w < sh.w0 + sh.nw; w++) {
+        const uint32_t raw = bits_at<Fr::N>(x.v, w * sh.c, sh.c) + carry;
+        const bool neg = raw > sh.nbk;
+        const uint32_t mag = neg ? (1u << sh.c) - raw : raw;
+        carry = neg ? 1u : 0u;
+        if (w >= sh.w0) digits[(uint64_t)(w - sh.w0) * sh.n_pad + i] = (uint16_t)(neg ? 0x10000u - mag : mag);
+    }
+}
+
+// visits every digit of window row `row` whose bucket falls in [lo, lo + rb): f(point index, bucket - lo, neg)
+template <class Fn>
+__device__ __forceinline__ void for_digits_in_range(const uint16_t* __restrict__ row, uint32_t n_pad, uint32_t lo, uint32_t rb,
+                                                    Fn&& f) {
+    const uint4* __restrict__ row4 = reinterpret_cast<const uint4*>(row);
+    const uint32_t nvec = n_pad >> 3;
+    for (uint32_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+        const uint4 q = row4[v];
+        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+        ZK_UNROLL
+        for (int k = 0; k < 8; k++) {
+            const uint32_t code = (wds[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+            bool neg;
+            const uint32_t mag = digit_mag(code, neg);
+            const uint32_t j = mag - 1 - lo;  // mag == 0 wraps to a huge value
+            if (j < rb) f(v * 8 + k, j, neg);
+        }
+    }
+}
+
+// grid = nw * nranges, workgroup (w, h) owns buckets [h*rb, (h+1)*rb) of window w
+template <class Tag>
+__global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restrict__ digits, MsmShape sh, uint32_t* __restrict__ counts,
+                                                        uint32_t* __restrict__ wg_total) {
+    ZK_DYN_SHARED(uint32_t, hist);  // rb counters (+ 1 total)
+    const uint32_t w = blockIdx.x / sh.nranges, h = blockIdx.x % sh.nranges;
+    const uint32_t lo = h * sh.rb;
+    for (uint32_t j = threadIdx.x; j <= sh.rb; j += blockDim.x) hist[j] = 0;
+    __syncthreads();
+    for_digits_in_range(digits + (uint64_t)w * sh.n_pad, sh.n_pad, lo, sh.rb,
+                        [&](uint32_t, uint32_t j, bool) { atomicAdd(&hist[j], 1u); });
+    __syncthreads();
+    uint32_t local = 0;
+    for (uint32_t j = threadIdx.x; j < sh.rb; j += blockDim.x) {
+        const uint32_t v = hist[j];
+        counts[(uint64_t)w * sh.nbk + lo + j] = v;
+        local += v;
+    }
+    atomicAdd(&hist[sh.rb], local);
+    __syncthreads();
+    if (threadIdx.x == 0) wg_total[blockIdx.x] = hist[sh.rb];
+}
+
+// same grid.  LDS: cur[rb] | part[1024] | bins[258]
+template <class Tag>
+__global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits, MsmShape sh,
+                                                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ wg_total,
+                                                           uint32_t* __restrict__ offs, uint32_t* __restrict__ order,
+                                                           uint32_t* __restrict__ sorted) {
+    ZK_DYN_SHARED(uint32_t, lds);
+    uint32_t* cur = lds;
+    uint32_t* part = lds + sh.rb;
+    uint32_t* bins = part + 1024;
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint32_t w = blockIdx.x / sh.nranges, h = blockIdx.x % sh.nranges;
+    const uint32_t lo = h * sh.rb;
+    const uint64_t gb0 = (uint64_t)w * sh.nbk + lo;
+    // base = number of entries owned by the workgroups before this one
+    uint32_t s = 0;
+    for (uint32_t g = tid; g < blockIdx.x; g += nth) s += wg_total[g];
+    part[tid] = s;
+    for (uint32_t j = tid; j < 258; j += nth) bins[j] = 0;
+    __syncthreads();
+    for (uint32_t d = nth >> 1; d > 0; d >>= 1) {
+        if (tid < d) part[tid] += part[tid + d];
+        __syncthreads();
+    }
+    const uint32_t base = part[0];
+    __syncthreads();
+    // exclusive scan of this range's counts: per-lane chunk sums, Hillis-Steele over the lanes, then refill
+    const uint32_t per = (sh.rb + nth - 1) / nth;
+    const uint32_t jlo = tid * per < sh.rb ? tid * per : sh.rb;
+    const uint32_t jhi = jlo + per < sh.rb ? jlo + per : sh.rb;
+    uint32_t sum = 0;
+    for (uint32_t j = jlo; j < jhi; j++) sum += counts[gb0 + j];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < nth; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = base + part[tid] - sum;
+    for (uint32_t j = jlo; j < jhi; j++) {
+        const uint32_t cnt = counts[gb0 + j];
+        cur[j] = run;
+        offs[gb0 + j] = run;
+        run += cnt;
+        atomicAdd(&bins[255u - (cnt < 255u ? cnt : 255u)], 1u);  // size classes, largest first
+    }
+    __syncthreads();
+    // order[]: the buckets of this range sorted by descending size class, so that the 64 buckets a wave of the
+    // accumulate kernel works on have (nearly) equal lengths
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < 256; k++) {
+            const uint32_t v = bins[k];
+            bins[k] = acc;
+            acc += v;
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = jlo; j < jhi; j++) {
+        const uint32_t cnt = counts[gb0 + j];
+        const uint32_t r = atomicAdd(&bins[255u - (cnt < 255u ? cnt : 255u)], 1u);
+        order[gb0 + r] = (uint32_t)(gb0 + j);
+    }
+    // scatter
+    for_digits_in_range(digits + (uint64_t)w * sh.n_pad, sh.n_pad, lo, sh.rb, [&](uint32_t i, uint32_t j, bool neg) {
+        const uint32_t p = atomicAdd(&cur[j], 1u);
+        sorted[p] = i | (neg ? 0x80000000u : 0u);
+    });
+}
+
+// Bucket accumulation: persistent waves pulling 64-bucket tasks from a queue, largest size class first
+// (longest-processing-time order, so the SIMDs finish together).  Task t = (rank r, range g): lane l sums
+// bucket order[g*rb + 64 r + l].  Buckets longer than sh.big_thresh (a few times the mean length: skewed
+// witnesses, e.g. the 25% of unit scalars of a Groth16 assignment) are not summed by one lane: they are cut
+// into segments of MSM_SEG entries appended to `seg_list` for msm_accumulate_big_kernel.
+constexpr uint32_t MSM_SEG = 2048;   // entries per cooperative segment (one wave: <= 32 adds per lane + a 6-level tree)
+
+// lanes per workgroup of the LDS tree kernels: 256 XYZZ points must fit the 64 KiB static LDS limit (G2: 384 B each)
+template <class C>
+constexpr uint32_t tree_lanes() {
+    return sizeof(XYZZ<C>) * 256 <= 48 * 1024 ? 256u : 128u;
+}
+
+struct MsmQueue {          // device-side control words, zeroed before every MSM
+    uint32_t head;         // next task
+    uint32_t nseg;         // segments appended
+    uint32_t nbig;         // big buckets appended
+    uint32_t pad;
+};
+struct MsmSeg {
+    uint32_t bucket, start, len, big_index;
+};
+
+template <class C>
+__device__ __forceinline__ void accumulate_slice(XYZZ<C>& acc, const Affine<C>* __restrict__ bases,
+                                                 const uint32_t* __restrict__ sorted, uint32_t start, uint32_t cnt,
+                                                 uint32_t stride) {
+    for (uint32_t k = 0; k < cnt; k += stride) {
+        const uint32_t e = sorted[start + k];
+        Affine<C> p = bases[e & 0x7fffffffu];
+        aff_neg_if(p, (e >> 31) != 0);
+        xyzz_add_mixed(acc, p);
+    }
+}
+
+// Persistent waves; every LANE streams buckets: when a lane finishes its bucket it takes the next one from the
+// wave's batch (LDS cursor), and the wave refills its batch from the global queue 64 buckets at a time.  Buckets
+// are visited largest size class first (rank-major over the per-range size-sorted lists), so the queue drains
+// into the shortest buckets and all SIMDs finish together; lanes never wait for a longer neighbour.
+constexpr uint32_t MSM_BATCH = 64;
+
+template <class C>
+__global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                      const uint32_t* __restrict__ offs, const uint32_t* __restrict__ counts,
+                                      const uint32_t* __restrict__ order, XYZZ<C>* __restrict__ buckets, MsmShape sh,
+                                      MsmQueue* __restrict__ q, MsmSeg* __restrict__ seg_list, uint32_t* __restrict__ big_list) {
+    __shared__ uint32_t s_next, s_end;
+    const uint32_t nrt = (uint32_t)sh.nw * sh.nranges;                 // ranges in this call
+    const uint32_t per_rank = nrt * 64;                                // positions per size rank
+    const uint32_t total = ((sh.rb + 63) / 64) * per_rank;             // visiting positions (ranges padded to 64 slots)
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) {
+        s_next = 0;
+        s_end = 0;
+    }
+    __syncthreads();
+    bool have = false, drained = false;
+    uint32_t gb = 0, pos = 0, end = 0;
+    XYZZ<C> acc;
+    xyzz_set_inf(acc);
+    for (;;) {
+        // ---- lanes without a bucket take the next position of the wave's batch
+        bool want_refill = false;
+        if (!have && !drained) {
+            const uint32_t i = atomicAdd(&s_next, 1u);
+            if (i < s_end) {
+                const uint32_t r = i / per_rank, rem = i % per_rank;
+                const uint32_t g = rem / 64, slot = r * 64 + (rem % 64);
+                if (slot < sh.rb) {
+                    gb = order[(uint64_t)g * sh.rb + slot];
+                    const uint32_t start = offs[gb], cnt = counts[gb];
+                    if (cnt > sh.big_thresh) {
+                        const uint32_t ns = (cnt + MSM_SEG - 1) / MSM_SEG;
+                        const uint32_t bi = atomicAdd(&q->nbig, 1u);
+                        const uint32_t s0 = atomicAdd(&q->nseg, ns);
+                        big_list[2 * bi] = gb;
+                        big_list[2 * bi + 1] = s0;
+                        for (uint32_t k = 0; k < ns; k++) {
+                            MsmSeg sg;
+                            sg.bucket = gb;
+                            sg.start = start + k * MSM_SEG;
+                            sg.len = (k + 1 == ns) ? cnt - k * MSM_SEG : MSM_SEG;
+                            sg.big_index = bi;
+                            seg_list[s0 + k] = sg;
+                        }
+                    } else if (cnt == 0) {
+                        xyzz_set_inf(acc);
+                        buckets[gb] = acc;
+                    } else {
+                        have = true;
+                        pos = start;
+                        end = start + cnt;
+                        xyzz_set_inf(acc);
+                    }
+                }
+            } else {
+                want_refill = true;
+            }
+        }
+        // ---- one mixed add for every lane that owns a bucket
+        if (have) {
+            const uint32_t e = sorted[pos];
+            Affine<C> p = bases[e & sh.idx_mask & 0x7fffffffu];
+            aff_neg_if(p, (e >> 31) != 0);
+            xyzz_add_mixed(acc, p);
+            if (++pos == end) {
+                buckets[gb] = acc;
+                have = false;
+            }
+        }
+        if (__syncthreads_count(want_refill) != 0) {   // wave-uniform
+            if (lane == 0) {
+                const uint32_t base = atomicAdd(&q->head, MSM_BATCH);
+                s_next = base < total ? base : total;
+                s_end = base + MSM_BATCH < total ? base + MSM_BATCH : total;
+            }
+            __syncthreads();
+            if (s_next >= s_end) drained = true;        // the global queue is empty: nothing left to take
+        }
+        if (__syncthreads_count(have || !drained) == 0) break;  // every lane has stored its last bucket
+    }
+}
+
+// One wave per segment of an oversized bucket: lane-strided partial sums + LDS tree.
+// Fixed grid; waves stride over the device-side segment list.
+template <class C>
+__global__ void __launch_bounds__(64) msm_accumulate_big_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                                const MsmQueue* __restrict__ q, const MsmSeg* __restrict__ seg_list,
+                                                                XYZZ<C>* __restrict__ seg_out) {
+    __shared__ XYZZ<C> sh[64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nseg = q->nseg;
+    for (uint32_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const MsmSeg sg = seg_list[s];
+        XYZZ<C> acc;
+        xyzz_set_inf(acc);
+        if (tid < sg.len) accumulate_slice<C>(acc, bases, sorted, sg.start + tid, sg.len - tid, 64);
+        sh[tid] = acc;
+        __syncthreads();
+        for (uint32_t d = 32; d > 0; d >>= 1) {
+            if (tid < d) {
+                XYZZ<C> b = sh[tid + d];
+                xyzz_add(acc, b);
+                sh[tid] = acc;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) seg_out[s] = acc;
+        __syncthreads();
+    }
+}
+
+// bucket = sum of its segments (one workgroup per oversized bucket; segment counts are small: cnt / MSM_SEG)
+template <class C>
+__global__ void __launch_bounds__(256) msm_combine_big_kernel(const MsmQueue* __restrict__ q, const uint32_t* __restrict__ big_list,
+                                                              const uint32_t* __restrict__ counts, const XYZZ<C>* __restrict__ seg_out,
+                                                              XYZZ<C>* __restrict__ buckets) {
+    constexpr uint32_t TL = tree_lanes<C>();
+    __shared__ XYZZ<C> sh[TL];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nbig = q->nbig;
+    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const uint32_t gb = big_list[2 * b], s0 = big_list[2 * b + 1];
+        const uint32_t ns = (counts[gb] + MSM_SEG - 1) / MSM_SEG;
+        XYZZ<C> acc;
+        xyzz_set_inf(acc);
+        for (uint32_t k = tid; k < ns; k += TL) {
+            XYZZ<C> v = seg_out[s0 + k];
+            xyzz_add(acc, v);
+        }
+        sh[tid] = acc;
+        __syncthreads();
+        for (uint32_t d = TL / 2; d > 0; d >>= 1) {
+            if (tid < d) {
+                XYZZ<C> v = sh[tid + d];
+                xyzz_add(acc, v);
+                sh[tid] = acc;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) buckets[gb] = acc;
+        __syncthreads();
+    }
+}
+
+// slice t of window w covers bucket indices [t*L, (t+1)*L) (weights index+1):
+//   X_t = sum_l (l+1) B_{tL+l} + [t*L] * sum_l B_{tL+l}
+template <class C>
+__global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restrict__ buckets, XYZZ<C>* __restrict__ out, uint32_t nbk, uint32_t L,
+                                  uint32_t slices_per_window, uint32_t nslices) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt >= nslices) return;
+    const uint32_t w = gt / slices_per_window, t = gt % slices_per_window;
+    XYZZ<C> run, wsum;
+    xyzz_set_inf(run);
+    xyzz_set_inf(wsum);
+    for (int l = (int)L - 1; l >= 0; l--) {
+        const uint32_t i = t * L + (uint32_t)l;
+        if (i < nbk) {
+            XYZZ<C> b = buckets[(uint64_t)w * nbk + i];
+            xyzz_add(run, b);
+        }
+        xyzz_add(wsum, run);
+    }
+    // wsum += [t*L] run   (MSB-first double-and-add on a <= 31-bit multiplier)
+    const uint32_t m = t * L;
+    if (m != 0 && !xyzz_is_inf(run)) {
+        XYZZ<C> acc;
+        xyzz_set_inf(acc);
+        for (int bit = 31 - __clz(m); bit >= 0; bit--) {
+            xyzz_dbl(acc);
+            if ((m >> bit) & 1) xyzz_add(acc, run);
+        }
+        xyzz_add(wsum, acc);
+    }
+    out[gt] = wsum;
+}
+
+// out[s*per_out + o] = sum of in[s*per_in + o*chunk .. +chunk), chunk = 256*E; one workgroup (256 lanes) per output
+template <class C>
+__global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<C>* __restrict__ in, XYZZ<C>* __restrict__ out, uint32_t per_in, uint32_t per_out,
+                               uint32_t E) {
+    constexpr uint32_t TL = tree_lanes<C>();
+    __shared__ XYZZ<C> sh[TL];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t s = blockIdx.x / per_out, o = blockIdx.x % per_out;
+    const uint32_t chunk = TL * E;
+    const uint32_t lo = o * chunk;
+    XYZZ<C> acc;
+    xyzz_set_inf(acc);
+    for (uint32_t k = 0; k < E; k++) {
+        const uint32_t i = lo + k * TL + tid;
+        if (i < per_in && i < lo + chunk) {
+            XYZZ<C> b = in[(uint64_t)s * per_in + i];
+            xyzz_add(acc, b);
+        }
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t d = TL / 2; d > 0; d >>= 1) {
+        if (tid < d) {
+            XYZZ<C> b = sh[tid + d];
+            xyzz_add(acc, b);
+            sh[tid] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[(uint64_t)s * per_out + o] = acc;
+}
+
+// out[i] = [k_i] G in affine form (k canonical).  Used to build seeded test / bench bases
+// (P_i = [k_i]G) and as the building block of fixed-base setup work.
+template <class C>
+__global__ void __launch_bounds__(64) fixed_base_mul_kernel(const Fe<typename C::Fr>* __restrict__ scalars, Affine<C>* __restrict__ out, uint32_t n) {
+    using Fr = typename C::Fr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<Fr> k = scalars[i];
+    Affine<C> g;
+    curve_generator(g);
+    XYZZ<C> acc;
+    xyzz_set_inf(acc);
+    for (int bit = 32 * Fr::N - 1; bit >= 0; bit--) {
+        xyzz_dbl(acc);
+        if ((word_at<Fr::N>(k.v, bit >> 5) >> (bit & 31)) & 1) xyzz_add_mixed(acc, g);
+    }
+    Affine<C> r;
+    xyzz_to_affine(r, acc);
+    out[i] = r;
+}
+
+}  // namespace zk

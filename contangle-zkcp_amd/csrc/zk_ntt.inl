@@ -1,6 +1,7 @@
 // NTT launch sequence (plan -> passes).  Included by zk_ntt_inst.cc, once per scalar field.
 #pragma once
 #include "zk_internal.h"
+#include "zk_ntt_kernels.h"
 namespace zk {
 // ------------------------------------------------------------------ NTT
 struct NttPlan {
@@ -180,4 +181,48 @@ int coset_run(Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st) {
     return ZK_OK;
 }
 
+
+template <class F>
+int vec_op_run(Fe<F>* a, const Fe<F>* b, const Fe<F>* c, uint64_t n, int op, const Fe<F>& s, hipStream_t st) {
+    if (n == 0) return ZK_OK;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;  // grid-stride: 16 workgroups per CU
+    ZK_LAUNCH((vec_op_kernel<F>), (unsigned)blocks, 256, 0, st, a, b, c, n, op, s);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+// ark-groth16 0.3 r1cs_to_qap.rs  R1CStoQAP::witness_map, from the point where a, b, c hold the evaluations
+// <A_i,z>, <B_i,z>, <C_i,z> on the size-m domain: seven NTTs and the pointwise glue, all in HBM.
+//   ifft(a); ifft(b); coset_fft(a); coset_fft(b); ifft(c); coset_fft(c);
+//   ab = a.b - c;  ab *= 1/Z_H(g);  coset_ifft(ab)            -> `a` holds h (m coefficients, Montgomery)
+template <class F>
+int witness_map_run(int field, Fe<F>* a, Fe<F>* b, Fe<F>* c, uint32_t logm, hipStream_t st) {
+    if (logm > (uint32_t)F::TWO_ADICITY || logm > 30) return ZK_ERR_INVALID_ARG;
+    const uint64_t m = 1ull << logm;
+    Fe<F> w, winv, gen, ginv, zinv, one;
+    for (int i = 0; i < F::N; i++) {
+        w.v[i] = F::ROOT[i];
+        gen.v[i] = F::GEN[i];
+    }
+    for (uint32_t i = logm; i < (uint32_t)F::TWO_ADICITY; i++) fe_sqr(w, w);
+    fe_inv(winv, w);
+    fe_inv(ginv, gen);
+    // Z_H(g) = g^m - 1 on the coset gH
+    Fe<F> gm = gen;
+    for (uint32_t i = 0; i < logm; i++) fe_sqr(gm, gm);
+    fe_one(one);
+    fe_sub(gm, gm, one);
+    fe_inv(zinv, gm);
+    Fe<F>* vs[3] = {a, b, c};
+    for (int k = 0; k < 3; k++) {
+        ZK_TRY(ntt_run<F>(field, vs[k], logm, winv, 1, st));   // ifft_in_place
+        ZK_TRY(coset_run<F>(vs[k], logm, gen, st));            // distribute_powers(g)
+        ZK_TRY(ntt_run<F>(field, vs[k], logm, w, 0, st));      // fft_in_place
+    }
+    ZK_TRY(vec_op_run<F>(a, b, c, m, VEC_QAP, zinv, st));
+    ZK_TRY(ntt_run<F>(field, a, logm, winv, 1, st));           // coset_ifft = ifft ; distribute_powers(g^-1)
+    ZK_TRY(coset_run<F>(a, logm, ginv, st));
+    return ZK_OK;
+}
 }  // namespace zk

@@ -120,6 +120,17 @@ int zk_ntt_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *om
 int zk_coset_mul(zk_field_t f, void *a_mont_host, uint32_t log_n, const void *g_mont_host);
 int zk_coset_mul_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *g_mont_host, void *hip_stream);
 
+/* ---- Groth16 witness map glue (ark-groth16 0.3 r1cs_to_qap.rs R1CStoQAP::witness_map), device buffers ----
+ * zk_vec_op_device: op 0 a*=b, 1 a-=b, 2 a+=b, 3 a*=scalar, 4 a=into_repr(a) (Montgomery -> canonical BigInt),
+ *                   5 a=from_repr(a), 6 a=(a*b-c)*scalar.  b / c / scalar may be NULL when the op does not use them.
+ * zk_groth16_witness_map_device: a, b, c hold the evaluations <A_i,z>, <B_i,z>, <C_i,z> on the size-2^log_m domain;
+ *   runs ifft, coset_fft (x3), ab - c, division by Z_H on the coset and coset_ifft entirely in HBM; on return `a`
+ *   holds the m coefficients of h (Montgomery), b and c are clobbered.  Feed a[0..m-1) to zk_msm_device with
+ *   scalars_are_montgomery = 1 for the h_query MSM. */
+int zk_vec_op_device(zk_field_t f, int op, void *a_dev, const void *b_dev, const void *c_dev, uint64_t n,
+                     const void *scalar_mont_host, void *hip_stream);
+int zk_groth16_witness_map_device(zk_field_t f, void *a_dev, void *b_dev, void *c_dev, uint32_t log_m, void *hip_stream);
+
 /* ---- host-side helpers a shim needs around the two kernels ---- */
 int zk_field_root_of_unity(zk_field_t f, uint32_t log_n, void *omega_mont_out);   /* ark group_gen / halo2 omega for size 2^log_n */
 int zk_field_multiplicative_generator(zk_field_t f, void *g_mont_out);            /* ark coset shift (7 BLS12-381 Fr, 5 BN254 Fr, 5 pasta) */

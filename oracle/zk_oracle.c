@@ -369,3 +369,28 @@ EXPORT void orc_distribute_powers(int field, uint64_t *a, size_t n, const uint64
     memcpy(&g, g_mont, 32);
     distribute_powers(&f, (fe_4 *)a, n, &g);
 }
+
+/* ark-groth16 0.3 r1cs_to_qap.rs R1CStoQAP::witness_map, from the evaluation vectors a, b, c (size 2^logm):
+ *   ifft(a), ifft(b), coset_fft(a), coset_fft(b), ab = a.b, ifft(c), coset_fft(c), ab -= c,
+ *   divide_by_vanishing_poly_on_coset_in_place(ab)  [ * (g^m - 1)^-1 ], coset_ifft(ab)  ->  h (written to a) */
+EXPORT void orc_groth16_witness_map(int field, uint64_t *a_, uint64_t *b_, uint64_t *c_, int logm, int threads) {
+    fctx_4 f = {&ORC_FIELDS[field]};
+    size_t m = (size_t)1 << logm;
+    fe_4 *a = (fe_4 *)a_, *b = (fe_4 *)b_, *c = (fe_4 *)c_;
+    orc_ark_fft(field, a_, logm, 1, threads);
+    orc_ark_fft(field, b_, logm, 1, threads);
+    orc_ark_fft(field, a_, logm, 2, threads);
+    orc_ark_fft(field, b_, logm, 2, threads);
+    for (size_t i = 0; i < m; i++) fe_mul_4(&f, &a[i], &a[i], &b[i]);
+    orc_ark_fft(field, c_, logm, 1, threads);
+    orc_ark_fft(field, c_, logm, 2, threads);
+    for (size_t i = 0; i < m; i++) fe_sub_4(&f, &a[i], &a[i], &c[i]);
+    fe_4 g, z, one;
+    memcpy(&g, f.c->gen_mont, 32);
+    fe_pow_u64_4(&f, &z, &g, (uint64_t)m);
+    fe_one_4(&f, &one);
+    fe_sub_4(&f, &z, &z, &one);
+    fe_inv_4(&f, &z, &z);
+    for (size_t i = 0; i < m; i++) fe_mul_4(&f, &a[i], &a[i], &z);
+    orc_ark_fft(field, a_, logm, 3, threads);
+}

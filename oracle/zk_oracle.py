@@ -232,3 +232,11 @@ def distribute_powers(field, a, g_mont):
     a = _u64(a).copy()
     lib().orc_distribute_powers(fid(field), _p(a), ctypes.c_size_t(a.shape[0]), _p(_u64(g_mont)))
     return a
+
+
+def groth16_witness_map(field, a, b, c, threads=1):
+    """ark-groth16 0.3 R1CStoQAP::witness_map restatement from the evaluation vectors; returns h (m coefficients)."""
+    a, b, c = _u64(a).copy(), _u64(b).copy(), _u64(c).copy()
+    logm = int(a.shape[0]).bit_length() - 1
+    lib().orc_groth16_witness_map(fid(field), _p(a), _p(b), _p(c), logm, threads)
+    return a

@@ -239,3 +239,53 @@ def check_msm_big_buckets(zk, cname, n=5200, window_bits=6):
     got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
     assert (got == orc.msm_ark(cname, pts, sc, threads=8)).all(), (cname, n)
     bases.free()
+
+
+# ------------------------------------------------------------------ Groth16 witness map
+def to_device(zk, arr):
+    """device buffer for the *_device entry points: a torch tensor on the GPU, or (under the CPU test emulator,
+    whose 'device memory' is host memory) a numpy copy"""
+    if zk.backend_info().startswith("emu"):
+        return np.ascontiguousarray(arr, dtype=np.uint64).copy()
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64)).cuda()
+
+
+def to_host(zk, buf):
+    if isinstance(buf, np.ndarray):
+        return buf
+    import torch
+    torch.cuda.synchronize()
+    return buf.cpu().numpy().view(np.uint64)
+
+
+def check_vec_ops(zk, name, n=1000):
+    a, b, c = rand_field(name, n, 1), rand_field(name, n, 2), rand_field(name, n, 3)
+    s = rand_field(name, 1, 4)[0]
+    fe = lambda op, x, y=None: np.stack([orc.fe_op(name, op, x[i], None if y is None else y[i]) for i in range(len(x))])
+    assert (to_host(zk, zk.vec_op(name, "mul", to_device(zk, a), to_device(zk, b))) == fe("mul", a, b)).all()
+    assert (to_host(zk, zk.vec_op(name, "sub", to_device(zk, a), to_device(zk, b))) == fe("sub", a, b)).all()
+    assert (to_host(zk, zk.vec_op(name, "add", to_device(zk, a), to_device(zk, b))) == fe("add", a, b)).all()
+    assert (to_host(zk, zk.vec_op(name, "scale", to_device(zk, a), scalar=s)) == fe("mul", a, np.tile(s, (n, 1)))).all()
+    assert (to_host(zk, zk.vec_op(name, "into_repr", to_device(zk, a))) == orc.from_mont(name, a)).all()
+    assert (to_host(zk, zk.vec_op(name, "from_repr", to_device(zk, orc.from_mont(name, a)))) == a).all()
+    q = to_host(zk, zk.vec_op(name, "qap", to_device(zk, a), to_device(zk, b), to_device(zk, c), scalar=s))
+    assert (q == fe("mul", fe("sub", fe("mul", a, b), c), np.tile(s, (n, 1)))).all()
+
+
+def check_witness_map(zk, name, logm, threads=8):
+    """a, b random evaluations; c = a.b on the first m-2 rows and random on the rest is NOT a valid witness, so
+    use c = a.b pointwise (valid QAP): h must have degree <= m-2 and match the oracle's restatement bit for bit."""
+    m = 1 << logm
+    a, b = rand_field(name, m, 11), rand_field(name, m, 12)
+    c = to_host(zk, zk.vec_op(name, "mul", to_device(zk, a), to_device(zk, b))).copy()
+    exp = orc.groth16_witness_map(name, a, b, c, threads=threads)
+    h = to_host(zk, zk.groth16_witness_map(name, to_device(zk, a), to_device(zk, b), to_device(zk, c)))
+    assert (h == exp).all(), (name, logm)
+    assert not h[m - 1].any()                    # deg h <= m - 2 for a satisfied system
+    assert h[: m - 1].any()
+    # an unsatisfied system (random c) still matches the oracle (no structural shortcut taken)
+    c2 = rand_field(name, m, 13)
+    exp2 = orc.groth16_witness_map(name, a, b, c2, threads=threads)
+    h2 = to_host(zk, zk.groth16_witness_map(name, to_device(zk, a), to_device(zk, b), to_device(zk, c2)))
+    assert (h2 == exp2).all()

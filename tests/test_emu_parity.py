@@ -70,3 +70,10 @@ def test_msm_window_sharding(zk):
 def test_msm_big_buckets(zk):
     ps.check_msm_big_buckets(zk, "Vesta")
     ps.check_msm_big_buckets(zk, "Bls381G1", n=2100, window_bits=4)
+
+
+def test_vec_ops_and_witness_map(zk):
+    ps.check_vec_ops(zk, "Bls381Fr", 300)
+    ps.check_vec_ops(zk, "PallasFp", 100)
+    ps.check_witness_map(zk, "Bls381Fr", 6)
+    ps.check_witness_map(zk, "Bn254Fr", 4)

@@ -68,6 +68,18 @@ def test_ntt_device_tensor_path(zk):
     assert (got == orc.halo2_best_fft(name, a, w, logn, threads=8)).all()
 
 
+@pytest.mark.parametrize("name", ps.NTT_FIELDS)
+def test_vec_ops(zk, name):
+    ps.check_vec_ops(zk, name, 5000)
+
+
+@pytest.mark.parametrize("name,logm", [("Bls381Fr", 10), ("Bls381Fr", 16), ("Bn254Fr", 13), ("PallasFp", 12), ("Bls381Fr", 20)])
+def test_groth16_witness_map(zk, name, logm):
+    """ark-groth16 witness_map (7 NTTs + pointwise glue) entirely in HBM vs the oracle's restatement; 2^20 is the
+    domain of the reference's own largest test (circuits-ark/src/encryption.rs:379)."""
+    ps.check_witness_map(zk, name, logm, threads=16)
+
+
 def test_msm_golden(zk):
     ps.check_msm_golden(zk)
 
