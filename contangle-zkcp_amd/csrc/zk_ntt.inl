@@ -149,7 +149,12 @@ int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_fl
         }
         const uint64_t tiles = (1ull << logn) >> (A.log_r + A.log_t);
         const uint32_t rt = 1u << (A.log_r + A.log_t);
-        unsigned blk = rt / 2 < 64 ? 64 : (rt / 2 > 256 ? 256 : rt / 2);
+        unsigned max_blk = 512;  // 8 waves per tile: measured best (tools/tune_ntt.py)
+        if (const char* e = getenv("ZK_NTT_BLOCK")) {
+            int v = atoi(e);
+            if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) max_blk = (unsigned)v;
+        }
+        unsigned blk = rt / 2 < 64 ? 64 : (rt / 2 > max_blk ? max_blk : rt / 2);
         const size_t shmem = (size_t)rt * sizeof(Fe<F>);
         if (shmem > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),

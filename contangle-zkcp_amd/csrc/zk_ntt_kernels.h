@@ -132,7 +132,7 @@ __device__ __forceinline__ void tw_get(Fe<F>& w, const Fe<F>* __restrict__ tw, u
 }
 
 template <class F>
-__global__ void __launch_bounds__(256) ntt_pass_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out, const Fe<F>* __restrict__ tw,
+__global__ void __launch_bounds__(1024) ntt_pass_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out, const Fe<F>* __restrict__ tw,
                                 NttPass A, Fe<F> scale) {
     ZK_DYN_SHARED(uint32_t, lds);
     constexpr int NL = F::N;
