@@ -81,8 +81,10 @@ API int zk_shutdown(void) {
     std::lock_guard<std::mutex> lk(g.mu);
     if (!g.inited) return ZK_OK;
     hipDeviceSynchronize();
-    for (auto& kv : g.bases)
+    for (auto& kv : g.bases) {
         if (kv.second.owned) hipFree(kv.second.dev);
+        if (kv.second.dev29) hipFree(kv.second.dev29);
+    }
     g.bases.clear();
     for (auto& kv : g.tw) hipFree(kv.second.dev);
     g.tw.clear();
@@ -145,7 +147,15 @@ API int zk_bases_upload(zk_curve_t c, const void* host, uint64_t n, uint64_t* ha
     HIP_TRY(hipMalloc(&dev, esz * (n ? n : 1)));
     if (n) HIP_TRY(hipMemcpy(dev, host, esz * n, hipMemcpyHostToDevice));
     const uint64_t h = g.next_handle++;
-    g.bases[h] = BasesEntry{(int)c, dev, n, true};
+    BasesEntry be{(int)c, dev, n, true, nullptr};
+    CURVE_SWITCH(c, {
+        int st = bases_prepare_run<C>(be);
+        if (st != ZK_OK) {
+            hipFree(dev);
+            return st;
+        }
+    });
+    g.bases[h] = be;
     *handle_out = h;
     return ZK_OK;
 }
@@ -153,9 +163,10 @@ API int zk_bases_adopt_device(zk_curve_t c, const void* dev, uint64_t n, uint64_
     std::lock_guard<std::mutex> lk(g.mu);
     ZK_TRY(require_init());
     if (!handle_out || !dev || !aligned16(dev)) return ZK_ERR_INVALID_ARG;
-    CURVE_SWITCH(c, (void)sizeof(C));
+    BasesEntry be{(int)c, const_cast<void*>(dev), n, false, nullptr};
+    CURVE_SWITCH(c, ZK_TRY(bases_prepare_run<C>(be)));
     const uint64_t h = g.next_handle++;
-    g.bases[h] = BasesEntry{(int)c, const_cast<void*>(dev), n, false};
+    g.bases[h] = be;
     *handle_out = h;
     return ZK_OK;
 }
@@ -164,10 +175,9 @@ API int zk_bases_free(uint64_t handle) {
     ZK_TRY(require_init());
     auto it = g.bases.find(handle);
     if (it == g.bases.end()) return ZK_ERR_BAD_HANDLE;
-    if (it->second.owned) {
-        hipDeviceSynchronize();
-        hipFree(it->second.dev);
-    }
+    if (it->second.owned || it->second.dev29) hipDeviceSynchronize();
+    if (it->second.owned) hipFree(it->second.dev);
+    if (it->second.dev29) hipFree(it->second.dev29);
     g.bases.erase(it);
     return ZK_OK;
 }

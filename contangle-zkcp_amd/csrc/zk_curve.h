@@ -15,22 +15,25 @@
 #include <type_traits>
 
 #include "zk_field.h"
+#include "zk_field29.h"
 
 namespace zk {
 
+// EXT: 1 = Fq, 2 = Fq2, 29 = the lazy 9 x 29-bit view of Fq used by the MSM bucket kernels (zk_curve29.h)
 template <class C>
-using Coord = std::conditional_t<C::EXT == 2, Fe2<typename C::Fq>, Fe<typename C::Fq>>;
+using Coord = std::conditional_t<C::EXT == 29, Fe29<typename C::Fq>,
+                                 std::conditional_t<C::EXT == 2, Fe2<typename C::Fq>, Fe<typename C::Fq>>>;
 template <class C>
 constexpr int coord_words() {
     return C::EXT * C::Fq::N;
 }
 
 template <class C>
-struct Affine {
+struct alignas(16) Affine {
     Coord<C> x, y;
 };
 template <class C>
-struct XYZZ {
+struct alignas(16) XYZZ {
     Coord<C> x, y, zz, zzz;
 };
 template <class C>

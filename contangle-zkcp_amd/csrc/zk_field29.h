@@ -1,0 +1,234 @@
+// "F29": the 254/255-bit base fields (Pasta Fp/Fq, BN254 Fq) as 9 unsaturated 29-bit limbs in u32 words, Montgomery
+// radix R' = 2^261, with LAZY reduction.  This is the arithmetic of the MSM bucket kernels on gfx950, where every VALU
+// instruction costs the same issue slot:
+//   * a column of partial products never overflows a 64-bit accumulator, so a product is ONE v_mad_u64_u32 (the
+//     saturated 32-bit form needs a MAD and a carry add), ~225 instead of ~290 instructions per multiplication;
+//   * additions are 9 independent limb adds, subtractions 9 limb subtract-and-bias pairs; no carry chains, no conditional
+//     subtraction of p.  Values are only ever reduced by the next Montgomery product.
+// The price is a bound discipline, stated here and machine-checked by tools/check_f29_bounds.py for every formula of
+// zk_curve29.h:
+//   limb bound  LB : every limb below the top one is <= LB            (u32 words; LB < 2^32)
+//   value bound VB : the integer  sum v[i] 2^(29 i)  is  < VB * p
+//   * fe29_mul(a, b):      requires 9 * LB(a) * LB(b) + 9 * 2^58 + 2^36 < 2^64;  result limbs < 2^29 ("strict"), value < VB(a) VB(b) p / 2^7 + p
+//   * fe29_add(a, b):      LB = LB(a) + LB(b), VB = VB(a) + VB(b)
+//   * fe29_sub<BIAS>(a,b): a - b + BIAS limb-wise; requires LB(b) <= k (2^29 - 1) [the k of the bias] and VB(b) + 2 <= its multiple of p;
+//                          LB = LB(a) + max limb of BIAS, VB = VB(a) + multiple
+//   * fe29_norm(a):        one parallel carry step: LB <= 2^29 + 6 ("N+"), value unchanged
+// Exact comparisons (is this value == 0 mod p?) never look at a lazy value directly: fe29_zero_filter() rejects all but
+// ~2^-25 of the non-zero cases from the low limb alone, and fe29_is_kp() decides the survivors on the fully carried integer.
+//
+// Data never changes Montgomery domain behind the caller's back: bases are converted once when they are uploaded
+// (x R  ->  x R'), results are converted back on the host (zk_msm.inl).
+#pragma once
+#include "zk_field.h"
+#include "zk_params29.h"
+
+namespace zk {
+
+constexpr uint32_t F29_MASK = (1u << 29) - 1;
+
+template <class P>
+struct alignas(4) Fe29 {
+    uint32_t v[9];
+};
+
+template <class P>
+ZK_HD void fe29_zero(Fe29<P>& r) {
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) r.v[i] = 0;
+}
+template <class P>
+ZK_HD void fe29_one(Fe29<P>& r) {
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) r.v[i] = F29<P>::ONE[i];
+}
+// all limbs zero: only the literal zero written by fe29_zero / a converted (0,0) identity satisfies this
+template <class P>
+ZK_HD bool fe29_is_literal_zero(const Fe29<P>& a) {
+    uint32_t o = 0;
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) o |= a.v[i];
+    return o == 0;
+}
+template <class P>
+ZK_HD void fe29_cmov(Fe29<P>& r, const Fe29<P>& a, bool sel) {
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) r.v[i] = sel ? a.v[i] : r.v[i];
+}
+
+// Montgomery product, R' = 2^261, carry-free columns (finely integrated product scanning)
+template <class P>
+ZK_HD void fe29_mul(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b) {
+    using K = F29<P>;
+    uint64_t acc = 0;
+    uint32_t m[9];
+    uint32_t out[9];
+    ZK_UNROLL
+    for (int k = 0; k < 17; k++) {
+        ZK_UNROLL
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 9) acc += (uint64_t)a.v[i] * b.v[j];
+        }
+        ZK_UNROLL
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            // m_i is known for i < k (first half) and for every i once k >= 9
+            if (j >= 1 && j < 9 && (i < k) && K::P[j] != 0) acc += (uint64_t)m[i] * K::P[j];
+        }
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * K::INV) & F29_MASK;
+            acc += (uint64_t)m[k] * K::P[0];
+            acc >>= 29;
+        } else {
+            out[k - 9] = (uint32_t)acc & F29_MASK;
+            acc >>= 29;
+        }
+    }
+    out[8] = (uint32_t)acc;
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) r.v[i] = out[i];
+}
+template <class P>
+ZK_HD void fe29_sqr(Fe29<P>& r, const Fe29<P>& a) {
+    fe29_mul(r, a, a);
+}
+
+template <class P>
+ZK_HD void fe29_add(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b) {
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+}
+// r = a - b + BIAS (BIAS = one of the F29<P>::BIAS* tables)
+template <class P>
+ZK_HD void fe29_sub(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b, const uint32_t (&bias)[9]) {
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + bias[i] - b.v[i];
+}
+// r = a - b - c - c + BIAS8K3
+template <class P>
+ZK_HD void fe29_sub3(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b, const Fe29<P>& c) {
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + F29<P>::BIAS8K3[i] - b.v[i] - c.v[i] - c.v[i];
+}
+// r = a - c - c + BIAS4K2
+template <class P>
+ZK_HD void fe29_sub2x(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& c) {
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + F29<P>::BIAS4K2[i] - c.v[i] - c.v[i];
+}
+// one parallel carry step: limbs below the top become <= 2^29 - 1 + 7
+template <class P>
+ZK_HD void fe29_norm(Fe29<P>& r, const Fe29<P>& a) {
+    uint32_t c[8];
+    ZK_UNROLL
+    for (int i = 0; i < 8; i++) c[i] = a.v[i] >> 29;
+    r.v[8] = a.v[8] + c[7];
+    ZK_UNROLL
+    for (int i = 7; i >= 1; i--) r.v[i] = (a.v[i] & F29_MASK) + c[i - 1];
+    r.v[0] = a.v[0] & F29_MASK;
+}
+// full serial carry: every limb below the top strictly < 2^29 (unique digits of the integer)
+template <class P>
+ZK_HD void fe29_carry(Fe29<P>& r, const Fe29<P>& a) {
+    uint32_t c = 0;
+    ZK_UNROLL
+    for (int i = 0; i < 8; i++) {
+        const uint32_t t = a.v[i] + c;
+        r.v[i] = t & F29_MASK;
+        c = t >> 29;
+    }
+    r.v[8] = a.v[8] + c;
+}
+// cheap necessary condition for "integer(a) == k p for some kmin <= k <= kmax": the low 29 bits of the integer decide k
+template <class P>
+ZK_HD bool fe29_zero_filter(const Fe29<P>& a, uint32_t kmin, uint32_t kmax, uint32_t& k) {
+    k = ((a.v[0] & F29_MASK) * F29<P>::P0INV) & F29_MASK;
+    return k - kmin <= kmax - kmin;
+}
+// exact: integer(a) == k p   (k < 20)
+template <class P>
+ZK_HD bool fe29_is_kp(const Fe29<P>& a, uint32_t k) {
+    Fe29<P> t;
+    fe29_carry(t, a);
+    uint32_t o = 0;
+    for (int i = 0; i < 9; i++) o |= t.v[i] ^ F29<P>::KP[k][i];
+    return o == 0;
+}
+// canonical representative in [0, p): strict limbs.  Slow (conversion / rare paths only); value must be < 20 p.
+template <class P>
+ZK_HD void fe29_canon(Fe29<P>& r, const Fe29<P>& a) {
+    Fe29<P> t;
+    fe29_carry(t, a);
+    for (int k = 19; k >= 1; k--) {
+        // if t >= k p: t -= k p   (afterwards t < p)
+        bool ge = true;
+        for (int i = 8; i >= 0; i--) {
+            if (t.v[i] != F29<P>::KP[k][i]) {
+                ge = t.v[i] > F29<P>::KP[k][i];
+                break;
+            }
+        }
+        if (ge) {
+            int32_t br = 0;
+            for (int i = 0; i < 8; i++) {
+                int32_t d = (int32_t)t.v[i] - (int32_t)F29<P>::KP[k][i] - br;
+                br = d < 0;
+                t.v[i] = (uint32_t)(d + (br << 29));
+            }
+            t.v[8] = t.v[8] - F29<P>::KP[k][8] - (uint32_t)br;
+            break;
+        }
+    }
+    r = t;
+}
+
+// ---- conversions between the caller's form (8 x u32, x R mod p, R = 2^256) and F29 (x R' mod p) ----
+// repack 256 bits into 29-bit limbs (no arithmetic)
+template <class P>
+ZK_HD void fe29_unpack(Fe29<P>& r, const Fe<P>& a) {
+    static_assert(P::N == 8, "F29 covers the 8-word fields");
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 5, off = bit & 31;
+        uint64_t x = a.v[w];
+        if (w + 1 < 8) x |= (uint64_t)a.v[w + 1] << 32;
+        r.v[i] = (uint32_t)(x >> off) & (i == 8 ? 0xffffffffu : F29_MASK);
+    }
+}
+// strict canonical F29 limbs (< p) -> 8 x u32
+template <class P>
+ZK_HD void fe29_pack(Fe<P>& r, const Fe29<P>& a) {
+    ZK_UNROLL
+    for (int w = 0; w < 8; w++) {
+        uint64_t x = 0;
+        ZK_UNROLL
+        for (int i = 0; i < 9; i++) {
+            const int lo = 29 * i - 32 * w;  // position of limb i relative to word w
+            if (lo > -29 && lo < 32) x |= lo >= 0 ? (uint64_t)a.v[i] << lo : (uint64_t)a.v[i] >> (-lo);
+        }
+        r.v[w] = (uint32_t)x;
+    }
+}
+// caller's Montgomery form -> F29 Montgomery form (strict limbs, value < 2p); 0 -> literal 0
+template <class P>
+ZK_HD void fe29_from_std(Fe29<P>& r, const Fe<P>& a) {
+    Fe29<P> t, c;
+    fe29_unpack(t, a);
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) c.v[i] = F29<P>::TO29[i];
+    fe29_mul(r, t, c);
+}
+// F29 (any lazy value < 20p after one multiplication: the product below brings it under 2p) -> caller's canonical form
+template <class P>
+ZK_HD void fe29_to_std(Fe<P>& r, const Fe29<P>& a) {
+    Fe29<P> t, c;
+    ZK_UNROLL
+    for (int i = 0; i < 9; i++) c.v[i] = F29<P>::FROM29[i];
+    fe29_norm(t, a);
+    fe29_mul(t, t, c);
+    fe29_canon(t, t);
+    fe29_pack(r, t);
+}
+
+}  // namespace zk

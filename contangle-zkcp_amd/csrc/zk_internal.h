@@ -40,9 +40,10 @@ struct DevBuf {
 };
 struct BasesEntry {
     int curve;
-    void* dev;
+    void* dev;     // affine points as uploaded (8 / 12 x u32 Montgomery words per coordinate)
     uint64_t n;
     bool owned;
+    void* dev29;   // the same points in the F29 view (zk_curve29.h), built once at upload for the 8-word G1 curves
 };
 struct TwKey {
     int field;
@@ -139,6 +140,8 @@ int witness_map_run(int field, Fe<F>* a, Fe<F>* b, Fe<F>* c, uint32_t logm, hipS
 template <class C>
 int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
             void* out_jac, hipStream_t st);
+template <class C>
+int bases_prepare_run(BasesEntry& be);   // build the resident F29 copy where the curve has one
 template <class C>
 int fixed_base_run(const Fe<typename C::Fr>* d_scalars, uint64_t n, Affine<C>* d_out, hipStream_t st);
 int msm_pick_c(uint64_t n, int requested);

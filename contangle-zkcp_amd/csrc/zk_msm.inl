@@ -9,9 +9,21 @@ inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// partial sums leave the device in the kernels' view CK of the curve (C itself, or its F29 view) and are brought back
+// to the caller's limb form here
 template <class C>
-int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
-            void* out_jac, hipStream_t st) {
+inline void partial_to_std(XYZZ<C>& r, const XYZZ<C>& p) {
+    r = p;
+}
+template <class C>
+inline void partial_to_std(XYZZ<C>& r, const XYZZ<C29<C>>& p) {
+    xyzz29_to_std<C>(r, p);
+}
+
+// C: the curve of the ABI call.  CK: the view the kernels compute in.  bases: device array of Affine<CK>.
+template <class C, class CK>
+int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
+                 void* out_jac, hipStream_t st) {
     Jacobian<C> result;
     memset(&g.prof, 0, sizeof g.prof);
     XYZZ<C> total;
@@ -27,6 +39,7 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
     g.prof.window_bits = c;
     g.prof.windows_total = nwin;
     g.prof.windows_done = w1 - w0;
+    g.prof.limb_bits = CK::EXT == 29 ? 29 : 32;
     if (n > 0 && w1 > w0) {
         if (n >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
         MsmShape sh;
@@ -60,7 +73,7 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         ZK_TRY(ws_get(g.msm_digits, (size_t)sh.n_pad * sh.nw * 2));
         uint16_t* digits = (uint16_t*)g.msm_digits.p;
         ZK_TRY(ws_get(g.msm_sorted, (size_t)n * sh.nw * 4));
-        ZK_TRY(ws_get(g.msm_buckets, (size_t)nbuckets * sizeof(XYZZ<C>)));
+        ZK_TRY(ws_get(g.msm_buckets, (size_t)nbuckets * sizeof(XYZZ<CK>)));
         uint32_t L = 8;
         if (const char* e = getenv("ZK_MSM_SLICE")) {
             int v = atoi(e);
@@ -69,8 +82,8 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         if (L > sh.nbk) L = sh.nbk;
         const uint32_t spw = (sh.nbk + L - 1) / L;
         const uint32_t nslices = spw * (uint32_t)sh.nw;
-        ZK_TRY(ws_get(g.msm_part_a, (size_t)nslices * sizeof(XYZZ<C>)));
-        ZK_TRY(ws_get(g.msm_part_b, ((size_t)nslices / 128 + (size_t)sh.nw + 8) * sizeof(XYZZ<C>)));
+        ZK_TRY(ws_get(g.msm_part_a, (size_t)nslices * sizeof(XYZZ<CK>)));
+        ZK_TRY(ws_get(g.msm_part_b, ((size_t)nslices / 128 + (size_t)sh.nw + 8) * sizeof(XYZZ<CK>)));
         if (!g.have_events) {
             for (auto& e : g.ev) HIP_TRY(hipEventCreate(&e));
             g.have_events = true;
@@ -93,7 +106,7 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         MsmQueue* q = (MsmQueue*)g.msm_queue.p;
         MsmSeg* seg_list = (MsmSeg*)(q + 1);
         uint32_t* big_list = (uint32_t*)(seg_list + max_seg);
-        ZK_TRY(ws_get(g.msm_seg_out, max_seg * sizeof(XYZZ<C>)));
+        ZK_TRY(ws_get(g.msm_seg_out, max_seg * sizeof(XYZZ<CK>)));
         HIP_TRY(hipMemsetAsync(q, 0, sizeof(MsmQueue), st));
         const uint32_t ntasks = (nwg * ((sh.rb + 63) / 64) * 64 + MSM_BATCH - 1) / MSM_BATCH;  // batches in the queue
         unsigned waves_per_simd = 4;
@@ -103,35 +116,35 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         }
         unsigned acc_grid = (g.num_cus > 0 ? (unsigned)g.num_cus : 256u) * 4u * waves_per_simd;
         if (acc_grid > ntasks) acc_grid = ntasks;
-        ZK_LAUNCH((msm_accumulate_kernel<C>), acc_grid, 64, 0, st, (const Affine<C>*)be.dev, (const uint32_t*)g.msm_sorted.p,
-                  (const uint32_t*)offs, (const uint32_t*)counts, (const uint32_t*)order, (XYZZ<C>*)g.msm_buckets.p, sh, q, seg_list,
+        ZK_LAUNCH((msm_accumulate_kernel<CK>), acc_grid, 64, 0, st, bases, (const uint32_t*)g.msm_sorted.p,
+                  (const uint32_t*)offs, (const uint32_t*)counts, (const uint32_t*)order, (XYZZ<CK>*)g.msm_buckets.p, sh, q, seg_list,
                   big_list);
         const unsigned big_grid = max_seg < 4096 ? (unsigned)max_seg : 4096u;
-        ZK_LAUNCH((msm_accumulate_big_kernel<C>), big_grid, 64, 0, st, (const Affine<C>*)be.dev, (const uint32_t*)g.msm_sorted.p,
-                  (const MsmQueue*)q, (const MsmSeg*)seg_list, (XYZZ<C>*)g.msm_seg_out.p);
-        ZK_LAUNCH((msm_combine_big_kernel<C>), big_grid < 64 ? big_grid : 64u, tree_lanes<C>(), 0, st, (const MsmQueue*)q, (const uint32_t*)big_list,
-                  (const uint32_t*)counts, (const XYZZ<C>*)g.msm_seg_out.p, (XYZZ<C>*)g.msm_buckets.p);
+        ZK_LAUNCH((msm_accumulate_big_kernel<CK>), big_grid, 64, 0, st, bases, (const uint32_t*)g.msm_sorted.p,
+                  (const MsmQueue*)q, (const MsmSeg*)seg_list, (XYZZ<CK>*)g.msm_seg_out.p);
+        ZK_LAUNCH((msm_combine_big_kernel<CK>), big_grid < 64 ? big_grid : 64u, tree_lanes<CK>(), 0, st, (const MsmQueue*)q, (const uint32_t*)big_list,
+                  (const uint32_t*)counts, (const XYZZ<CK>*)g.msm_seg_out.p, (XYZZ<CK>*)g.msm_buckets.p);
         HIP_TRY(hipEventRecord(g.ev[4], st));
-        ZK_LAUNCH((msm_reduce_kernel<C>), (nslices + 63) / 64, 64, 0, st, (const XYZZ<C>*)g.msm_buckets.p,
-                  (XYZZ<C>*)g.msm_part_a.p, sh.nbk, L, spw, nslices);
+        ZK_LAUNCH((msm_reduce_kernel<CK>), (nslices + 63) / 64, 64, 0, st, (const XYZZ<CK>*)g.msm_buckets.p,
+                  (XYZZ<CK>*)g.msm_part_a.p, sh.nbk, L, spw, nslices);
         // tree-sum the slices of each window until <= 8 remain
-        XYZZ<C>* cur = (XYZZ<C>*)g.msm_part_a.p;
-        XYZZ<C>* nxt = (XYZZ<C>*)g.msm_part_b.p;
+        XYZZ<CK>* cur = (XYZZ<CK>*)g.msm_part_a.p;
+        XYZZ<CK>* nxt = (XYZZ<CK>*)g.msm_part_b.p;
         uint32_t per = spw;
         while (per > 8) {
             const uint32_t E = per >= 1024 ? 4 : 1;
-            const uint32_t chunk = tree_lanes<C>() * E;
+            const uint32_t chunk = tree_lanes<CK>() * E;
             const uint32_t per_out = (per + chunk - 1) / chunk;
-            ZK_LAUNCH((msm_sum_kernel<C>), (unsigned)sh.nw * per_out, tree_lanes<C>(), 0, st, (const XYZZ<C>*)cur, nxt, per, per_out, E);
+            ZK_LAUNCH((msm_sum_kernel<CK>), (unsigned)sh.nw * per_out, tree_lanes<CK>(), 0, st, (const XYZZ<CK>*)cur, nxt, per, per_out, E);
             per = per_out;
-            XYZZ<C>* t = cur;
+            XYZZ<CK>* t = cur;
             cur = nxt;
             nxt = t;
         }
         HIP_TRY(hipEventRecord(g.ev[5], st));
         HIP_TRY(hipGetLastError());
-        std::vector<XYZZ<C>> host((size_t)sh.nw * per);
-        HIP_TRY(hipMemcpyAsync(host.data(), cur, host.size() * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, st));
+        std::vector<XYZZ<CK>> host((size_t)sh.nw * per);
+        HIP_TRY(hipMemcpyAsync(host.data(), cur, host.size() * sizeof(XYZZ<CK>), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const double t0 = now_ms();
         // Horner over this call's windows, high to low, then the shift by 2^(c*w0) -- on 64-bit host limbs
@@ -140,7 +153,9 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
         for (int w = sh.nw - 1; w >= 0; w--) {
             for (int k = 0; k < c; k++) xyzz_dbl(htotal);
             for (uint32_t i = 0; i < per; i++) {
-                to_host<C>(hp, host[(size_t)w * per + i]);
+                XYZZ<C> ps;
+                partial_to_std<C>(ps, host[(size_t)w * per + i]);
+                to_host<C>(hp, ps);
                 xyzz_add(htotal, hp);
             }
         }
@@ -160,6 +175,44 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
     return ZK_OK;
 }
 
+
+// the 8-word G1 curves (Pallas, Vesta, BN254 G1) run their bucket arithmetic in the F29 view
+template <class C>
+constexpr bool has_f29() {
+    return C::EXT == 1 && C::Fq::N == 8;
+}
+inline bool f29_enabled() {
+    const char* e = getenv("ZK_MSM_F29");   // "0" forces the saturated 32-bit path (A/B measurements, tests)
+    return !(e && e[0] == '0');
+}
+
+template <class C>
+int bases_prepare_run(BasesEntry& be) {
+    be.dev29 = nullptr;
+    if constexpr (has_f29<C>()) {
+        if (be.n == 0) return ZK_OK;
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, sizeof(Affine<C29<C>>) * be.n));
+        ZK_LAUNCH((bases_to29_kernel<C>), (unsigned)((be.n + 255) / 256), 256, 0, (hipStream_t)0, (const Affine<C>*)be.dev,
+                  (Affine<C29<C>>*)d, be.n);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess) {
+            hipFree(d);
+            return ZK_ERR_HIP;
+        }
+        be.dev29 = d;
+    }
+    return ZK_OK;
+}
+
+template <class C>
+int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
+            void* out_jac, hipStream_t st) {
+    if constexpr (has_f29<C>()) {
+        if (be.dev29 && f29_enabled())
+            return msm_run_impl<C, C29<C>>((const Affine<C29<C>>*)be.dev29, d_scalars, n, mont, opts, out_jac, st);
+    }
+    return msm_run_impl<C, C>((const Affine<C>*)be.dev, d_scalars, n, mont, opts, out_jac, st);
+}
 
 template <class C>
 int fixed_base_run(const Fe<typename C::Fr>* d_scalars, uint64_t n, Affine<C>* d_out, hipStream_t st) {

@@ -11,6 +11,7 @@
 #include "zk_rt.h"
 // (zk_rt.h first: it brings in the HIP runtime or the test emulator)
 #include "zk_curve.h"
+#include "zk_curve29.h"
 
 namespace zk {
 
@@ -449,6 +450,17 @@ __global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<C>* __restrict_
         __syncthreads();
     }
     if (tid == 0) out[(uint64_t)s * per_out + o] = acc;
+}
+
+// bases as uploaded (x R, 8 x u32 per coordinate)  ->  the F29 view the bucket kernels use (x R', 9 x 29-bit limbs)
+template <class C>
+__global__ void __launch_bounds__(256) bases_to29_kernel(const Affine<C>* __restrict__ in, Affine<C29<C>>* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<C> p = in[i];
+    Affine<C29<C>> q;
+    aff29_from_std(q, p);
+    out[i] = q;
 }
 
 // out[i] = [k_i] G in affine form (k canonical).  Used to build seeded test / bench bases
