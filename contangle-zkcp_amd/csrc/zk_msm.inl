@@ -109,7 +109,8 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         ZK_TRY(ws_get(g.msm_seg_out, max_seg * sizeof(XYZZ<CK>)));
         HIP_TRY(hipMemsetAsync(q, 0, sizeof(MsmQueue), st));
         const uint32_t ntasks = (nwg * ((sh.rb + 63) / 64) * 64 + MSM_BATCH - 1) / MSM_BATCH;  // batches in the queue
-        unsigned waves_per_simd = 4;
+        // resident waves per SIMD: the F29 kernel holds 138 VGPRs (3 fit), the 32-bit one 119 (4 fit); tools/tune_msm.py
+        unsigned waves_per_simd = CK::EXT == 29 ? 3 : 4;
         if (const char* e = getenv("ZK_MSM_WAVES")) {
             int v = atoi(e);
             if (v >= 1 && v <= 8) waves_per_simd = (unsigned)v;

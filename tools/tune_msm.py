@@ -20,7 +20,7 @@ torch.cuda.synchronize()
 bases = zk.Bases(curve, device_tensor=d_pts, n=n)
 d_sc = torch.from_numpy(ps.scalars_for(curve, n, 0xC0DE).view(np.int64)).cuda()
 ref = None
-grid = {"ZK_MSM_C": ["16", "15", "14", "13"], "ZK_MSM_SLICE": ["2", "4", "8", "16"], "ZK_MSM_WAVES": ["2", "4", "8"]}
+grid = {"ZK_MSM_C": ["16", "15"], "ZK_MSM_SLICE": ["4", "8", "16"], "ZK_MSM_WAVES": ["1", "2", "3", "4"]}
 base = {"ZK_MSM_C": "16", "ZK_MSM_SLICE": "8", "ZK_MSM_WAVES": "4"}
 configs = [dict(base)]
 for k, vals in grid.items():
