@@ -48,7 +48,7 @@ class MsmOpts(ctypes.Structure):
 class MsmProfile(ctypes.Structure):
     _fields_ = [(k, ctypes.c_float) for k in ("digits_ms", "hist_ms", "scatter_ms", "accumulate_ms", "reduce_ms",
                                               "host_tail_ms", "total_ms")] + \
-               [(k, ctypes.c_int) for k in ("window_bits", "windows_total", "windows_done", "limb_bits")]
+               [(k, ctypes.c_int) for k in ("window_bits", "windows_total", "windows_done", "groups", "limb_bits")]
 
 
 _lib = None

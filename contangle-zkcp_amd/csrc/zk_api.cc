@@ -94,6 +94,8 @@ API int zk_shutdown(void) {
         ws_free(*b);
     if (g.have_events) {
         for (auto& e : g.ev) hipEventDestroy(e);
+        if (g.aux_stream) hipStreamDestroy(g.aux_stream);
+        g.aux_stream = nullptr;
         g.have_events = false;
     }
     g.inited = false;

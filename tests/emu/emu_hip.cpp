@@ -127,6 +127,12 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
     return hipSuccess;
 }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned) {
+    *st = (hipStream_t)1;
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "emu"; }

@@ -88,6 +88,10 @@ hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
 hipError_t hipStreamSynchronize(hipStream_t st);
+enum { hipStreamNonBlocking = 1 };
+hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t st);
+hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned flags);
 hipError_t hipDeviceSynchronize();
 hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t e);

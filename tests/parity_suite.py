@@ -299,3 +299,24 @@ def check_witness_map(zk, name, logm, threads=8):
     exp2 = orc.groth16_witness_map(name, a, b, c2, threads=threads)
     h2 = to_host(zk, zk.groth16_witness_map(name, to_device(zk, a), to_device(zk, b), to_device(zk, c2)))
     assert (h2 == exp2).all()
+
+
+def check_msm_groups(zk, cname, n, window_bits):
+    """the window-group pipeline (two streams) gives the same point for every group count, sharded or not"""
+    pts = bases_for(cname, n)
+    sc = scalars_for(cname, n, 41, realistic=True)
+    exp = orc.msm_ark(cname, pts, sc, threads=8)
+    bases = zk.Bases(cname, pts)
+    W = zk.msm_window_count(cname, n, window_bits)
+    try:
+        for groups in (1, 2, 3, 5, 8):
+            os.environ["ZK_MSM_GROUPS"] = str(groups)
+            got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
+            assert (got == exp).all(), (cname, groups)
+            assert zk.msm_last_profile()["groups"] == min(groups, W)
+            lo = zk.msm(bases, sc, window_bits=window_bits, windows=(0, W // 2))
+            hi = zk.msm(bases, sc, window_bits=window_bits, windows=(W // 2, W))
+            assert (affine_of(zk, cname, zk.point_add(cname, lo, hi)) == exp).all(), (cname, groups, "sharded")
+    finally:
+        os.environ.pop("ZK_MSM_GROUPS", None)
+    bases.free()

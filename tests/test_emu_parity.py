@@ -77,3 +77,8 @@ def test_vec_ops_and_witness_map(zk):
     ps.check_vec_ops(zk, "PallasFp", 100)
     ps.check_witness_map(zk, "Bls381Fr", 6)
     ps.check_witness_map(zk, "Bn254Fr", 4)
+
+
+def test_msm_window_groups(zk):
+    ps.check_msm_groups(zk, "Vesta", 200, 5)
+    ps.check_msm_groups(zk, "Bls381G1", 90, 7)
