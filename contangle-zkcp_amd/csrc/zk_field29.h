@@ -1,5 +1,5 @@
-// "F29": the 254/255-bit base fields (Pasta Fp/Fq, BN254 Fq) as 9 unsaturated 29-bit limbs in u32 words, Montgomery
-// radix R' = 2^261, with LAZY reduction.  This is the arithmetic of the MSM bucket kernels on gfx950, where every VALU
+// "F29": a base field as L unsaturated W-bit limbs in u32 words -- 9 x 29 bits (R' = 2^261) for the 254/255-bit fields
+// (Pasta Fp/Fq, BN254 Fq), 14 x 28 bits (R' = 2^392) for BLS12-381 Fq -- Montgomery radix R' = 2^(W L), with LAZY reduction.  This is the arithmetic of the MSM bucket kernels on gfx950, where every VALU
 // instruction costs the same issue slot:
 //   * a column of partial products never overflows a 64-bit accumulator, so a product is ONE v_mad_u64_u32 (the
 //     saturated 32-bit form needs a MAD and a carry add), ~225 instead of ~290 instructions per multiplication;
@@ -25,69 +25,73 @@
 
 namespace zk {
 
-constexpr uint32_t F29_MASK = (1u << 29) - 1;
-
 template <class P>
 struct alignas(4) Fe29 {
-    uint32_t v[9];
+    uint32_t v[F29<P>::L];
 };
+template <class P>
+constexpr uint32_t f29_mask() {
+    return (1u << F29<P>::W) - 1;
+}
 
 template <class P>
 ZK_HD void fe29_zero(Fe29<P>& r) {
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) r.v[i] = 0;
+    for (int i = 0; i < F29<P>::L; i++) r.v[i] = 0;
 }
 template <class P>
 ZK_HD void fe29_one(Fe29<P>& r) {
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) r.v[i] = F29<P>::ONE[i];
+    for (int i = 0; i < F29<P>::L; i++) r.v[i] = F29<P>::ONE[i];
 }
 // all limbs zero: only the literal zero written by fe29_zero / a converted (0,0) identity satisfies this
 template <class P>
 ZK_HD bool fe29_is_literal_zero(const Fe29<P>& a) {
     uint32_t o = 0;
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) o |= a.v[i];
+    for (int i = 0; i < F29<P>::L; i++) o |= a.v[i];
     return o == 0;
 }
 template <class P>
 ZK_HD void fe29_cmov(Fe29<P>& r, const Fe29<P>& a, bool sel) {
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) r.v[i] = sel ? a.v[i] : r.v[i];
+    for (int i = 0; i < F29<P>::L; i++) r.v[i] = sel ? a.v[i] : r.v[i];
 }
 
 // Montgomery product, R' = 2^261, carry-free columns (finely integrated product scanning)
 template <class P>
 ZK_HD void fe29_mul(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b) {
     using K = F29<P>;
+    constexpr int L = K::L, W = K::W;
+    constexpr uint32_t MASK = (1u << W) - 1;
     uint64_t acc = 0;
-    uint32_t m[9];
-    uint32_t out[9];
+    uint32_t m[L];
+    uint32_t out[L];
     ZK_UNROLL
-    for (int k = 0; k < 17; k++) {
+    for (int k = 0; k < 2 * L - 1; k++) {
         ZK_UNROLL
-        for (int i = 0; i < 9; i++) {
+        for (int i = 0; i < L; i++) {
             const int j = k - i;
-            if (j >= 0 && j < 9) acc += (uint64_t)a.v[i] * b.v[j];
+            if (j >= 0 && j < L) acc += (uint64_t)a.v[i] * b.v[j];
         }
         ZK_UNROLL
-        for (int i = 0; i < 9; i++) {
+        for (int i = 0; i < L; i++) {
             const int j = k - i;
-            // m_i is known for i < k (first half) and for every i once k >= 9
-            if (j >= 1 && j < 9 && (i < k) && K::P[j] != 0) acc += (uint64_t)m[i] * K::P[j];
+            // m_i is known for i < k (first half) and for every i once k >= L
+            if (j >= 1 && j < L && (i < k) && K::P[j] != 0) acc += (uint64_t)m[i] * K::P[j];
         }
-        if (k < 9) {
-            m[k] = ((uint32_t)acc * K::INV) & F29_MASK;
+        if (k < L) {
+            m[k] = ((uint32_t)acc * K::INV) & MASK;
             acc += (uint64_t)m[k] * K::P[0];
-            acc >>= 29;
+            acc >>= W;
         } else {
-            out[k - 9] = (uint32_t)acc & F29_MASK;
-            acc >>= 29;
+            out[k - L] = (uint32_t)acc & MASK;
+            acc >>= W;
         }
     }
-    out[8] = (uint32_t)acc;
+    out[L - 1] = (uint32_t)acc;
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) r.v[i] = out[i];
+    for (int i = 0; i < L; i++) r.v[i] = out[i];
 }
 template <class P>
 ZK_HD void fe29_sqr(Fe29<P>& r, const Fe29<P>& a) {
@@ -97,53 +101,57 @@ ZK_HD void fe29_sqr(Fe29<P>& r, const Fe29<P>& a) {
 template <class P>
 ZK_HD void fe29_add(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b) {
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    for (int i = 0; i < F29<P>::L; i++) r.v[i] = a.v[i] + b.v[i];
 }
 // r = a - b + BIAS (BIAS = one of the F29<P>::BIAS* tables)
 template <class P>
-ZK_HD void fe29_sub(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b, const uint32_t (&bias)[9]) {
+ZK_HD void fe29_sub(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b, const uint32_t (&bias)[F29<P>::L]) {
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + bias[i] - b.v[i];
+    for (int i = 0; i < F29<P>::L; i++) r.v[i] = a.v[i] + bias[i] - b.v[i];
 }
 // r = a - b - c - c + BIAS8K3
 template <class P>
 ZK_HD void fe29_sub3(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b, const Fe29<P>& c) {
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + F29<P>::BIAS8K3[i] - b.v[i] - c.v[i] - c.v[i];
+    for (int i = 0; i < F29<P>::L; i++) r.v[i] = a.v[i] + F29<P>::BIAS8K3[i] - b.v[i] - c.v[i] - c.v[i];
 }
 // r = a - c - c + BIAS4K2
 template <class P>
 ZK_HD void fe29_sub2x(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& c) {
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + F29<P>::BIAS4K2[i] - c.v[i] - c.v[i];
+    for (int i = 0; i < F29<P>::L; i++) r.v[i] = a.v[i] + F29<P>::BIAS4K2[i] - c.v[i] - c.v[i];
 }
-// one parallel carry step: limbs below the top become <= 2^29 - 1 + 7
+// one parallel carry step: limbs below the top become <= 2^W - 1 + (2^(32-W) - 1)
 template <class P>
 ZK_HD void fe29_norm(Fe29<P>& r, const Fe29<P>& a) {
-    uint32_t c[8];
+    constexpr int L = F29<P>::L, W = F29<P>::W;
+    constexpr uint32_t MASK = (1u << W) - 1;
+    uint32_t c[L - 1];
     ZK_UNROLL
-    for (int i = 0; i < 8; i++) c[i] = a.v[i] >> 29;
-    r.v[8] = a.v[8] + c[7];
+    for (int i = 0; i < L - 1; i++) c[i] = a.v[i] >> W;
+    r.v[L - 1] = a.v[L - 1] + c[L - 2];
     ZK_UNROLL
-    for (int i = 7; i >= 1; i--) r.v[i] = (a.v[i] & F29_MASK) + c[i - 1];
-    r.v[0] = a.v[0] & F29_MASK;
+    for (int i = L - 2; i >= 1; i--) r.v[i] = (a.v[i] & MASK) + c[i - 1];
+    r.v[0] = a.v[0] & MASK;
 }
-// full serial carry: every limb below the top strictly < 2^29 (unique digits of the integer)
+// full serial carry: every limb below the top strictly < 2^W (unique digits of the integer)
 template <class P>
 ZK_HD void fe29_carry(Fe29<P>& r, const Fe29<P>& a) {
+    constexpr int L = F29<P>::L, W = F29<P>::W;
+    constexpr uint32_t MASK = (1u << W) - 1;
     uint32_t c = 0;
     ZK_UNROLL
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < L - 1; i++) {
         const uint32_t t = a.v[i] + c;
-        r.v[i] = t & F29_MASK;
-        c = t >> 29;
+        r.v[i] = t & MASK;
+        c = t >> W;
     }
-    r.v[8] = a.v[8] + c;
+    r.v[L - 1] = a.v[L - 1] + c;
 }
 // cheap necessary condition for "integer(a) == k p for some kmin <= k <= kmax": the low 29 bits of the integer decide k
 template <class P>
 ZK_HD bool fe29_zero_filter(const Fe29<P>& a, uint32_t kmin, uint32_t kmax, uint32_t& k) {
-    k = ((a.v[0] & F29_MASK) * F29<P>::P0INV) & F29_MASK;
+    k = ((a.v[0] & f29_mask<P>()) * F29<P>::P0INV) & f29_mask<P>();
     return k - kmin <= kmax - kmin;
 }
 // exact: integer(a) == k p   (k < 20)
@@ -152,7 +160,7 @@ ZK_HD bool fe29_is_kp(const Fe29<P>& a, uint32_t k) {
     Fe29<P> t;
     fe29_carry(t, a);
     uint32_t o = 0;
-    for (int i = 0; i < 9; i++) o |= t.v[i] ^ F29<P>::KP[k][i];
+    for (int i = 0; i < F29<P>::L; i++) o |= t.v[i] ^ F29<P>::KP[k][i];
     return o == 0;
 }
 // canonical representative in [0, p): strict limbs.  Slow (conversion / rare paths only); value must be < 20 p.
@@ -163,7 +171,7 @@ ZK_HD void fe29_canon(Fe29<P>& r, const Fe29<P>& a) {
     for (int k = 19; k >= 1; k--) {
         // if t >= k p: t -= k p   (afterwards t < p)
         bool ge = true;
-        for (int i = 8; i >= 0; i--) {
+        for (int i = F29<P>::L - 1; i >= 0; i--) {
             if (t.v[i] != F29<P>::KP[k][i]) {
                 ge = t.v[i] > F29<P>::KP[k][i];
                 break;
@@ -171,12 +179,12 @@ ZK_HD void fe29_canon(Fe29<P>& r, const Fe29<P>& a) {
         }
         if (ge) {
             int32_t br = 0;
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < F29<P>::L - 1; i++) {
                 int32_t d = (int32_t)t.v[i] - (int32_t)F29<P>::KP[k][i] - br;
                 br = d < 0;
-                t.v[i] = (uint32_t)(d + (br << 29));
+                t.v[i] = (uint32_t)(d + (br << F29<P>::W));
             }
-            t.v[8] = t.v[8] - F29<P>::KP[k][8] - (uint32_t)br;
+            t.v[F29<P>::L - 1] = t.v[F29<P>::L - 1] - F29<P>::KP[k][F29<P>::L - 1] - (uint32_t)br;
             break;
         }
     }
@@ -184,28 +192,30 @@ ZK_HD void fe29_canon(Fe29<P>& r, const Fe29<P>& a) {
 }
 
 // ---- conversions between the caller's form (8 x u32, x R mod p, R = 2^256) and F29 (x R' mod p) ----
-// repack 256 bits into 29-bit limbs (no arithmetic)
+// repack the caller's 32-bit words into W-bit limbs (no arithmetic)
 template <class P>
 ZK_HD void fe29_unpack(Fe29<P>& r, const Fe<P>& a) {
-    static_assert(P::N == 8, "F29 covers the 8-word fields");
+    constexpr int L = F29<P>::L, W = F29<P>::W, N = P::N;
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) {
-        const int bit = 29 * i, w = bit >> 5, off = bit & 31;
-        uint64_t x = a.v[w];
-        if (w + 1 < 8) x |= (uint64_t)a.v[w + 1] << 32;
-        r.v[i] = (uint32_t)(x >> off) & (i == 8 ? 0xffffffffu : F29_MASK);
+    for (int i = 0; i < L; i++) {
+        const int bit = W * i, w = bit >> 5, off = bit & 31;
+        uint64_t x = 0;
+        if (w < N) x = a.v[w];
+        if (w + 1 < N) x |= (uint64_t)a.v[w + 1] << 32;
+        r.v[i] = (uint32_t)(x >> off) & (i == L - 1 ? 0xffffffffu : (1u << W) - 1);
     }
 }
-// strict canonical F29 limbs (< p) -> 8 x u32
+// strict canonical limbs (< p) -> the caller's 32-bit words
 template <class P>
 ZK_HD void fe29_pack(Fe<P>& r, const Fe29<P>& a) {
+    constexpr int L = F29<P>::L, W = F29<P>::W, N = P::N;
     ZK_UNROLL
-    for (int w = 0; w < 8; w++) {
+    for (int w = 0; w < N; w++) {
         uint64_t x = 0;
         ZK_UNROLL
-        for (int i = 0; i < 9; i++) {
-            const int lo = 29 * i - 32 * w;  // position of limb i relative to word w
-            if (lo > -29 && lo < 32) x |= lo >= 0 ? (uint64_t)a.v[i] << lo : (uint64_t)a.v[i] >> (-lo);
+        for (int i = 0; i < L; i++) {
+            const int lo = W * i - 32 * w;  // position of limb i relative to word w
+            if (lo > -W && lo < 32) x |= lo >= 0 ? (uint64_t)a.v[i] << lo : (uint64_t)a.v[i] >> (-lo);
         }
         r.v[w] = (uint32_t)x;
     }
@@ -216,7 +226,7 @@ ZK_HD void fe29_from_std(Fe29<P>& r, const Fe<P>& a) {
     Fe29<P> t, c;
     fe29_unpack(t, a);
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) c.v[i] = F29<P>::TO29[i];
+    for (int i = 0; i < F29<P>::L; i++) c.v[i] = F29<P>::TO29[i];
     fe29_mul(r, t, c);
 }
 // F29 (any lazy value < 20p after one multiplication: the product below brings it under 2p) -> caller's canonical form
@@ -224,7 +234,7 @@ template <class P>
 ZK_HD void fe29_to_std(Fe<P>& r, const Fe29<P>& a) {
     Fe29<P> t, c;
     ZK_UNROLL
-    for (int i = 0; i < 9; i++) c.v[i] = F29<P>::FROM29[i];
+    for (int i = 0; i < F29<P>::L; i++) c.v[i] = F29<P>::FROM29[i];
     fe29_norm(t, a);
     fe29_mul(t, t, c);
     fe29_canon(t, t);

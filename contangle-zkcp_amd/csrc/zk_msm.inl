@@ -242,10 +242,11 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
 }
 
 
-// the 8-word G1 curves (Pallas, Vesta, BN254 G1) run their bucket arithmetic in the F29 view
+// the G1 curves (Pallas, Vesta, BN254 G1: 9 x 29-bit limbs; BLS12-381 G1: 14 x 28) run their bucket arithmetic in the
+// lazy-limb view
 template <class C>
 constexpr bool has_f29() {
-    return C::EXT == 1 && C::Fq::N == 8;
+    return C::EXT == 1;
 }
 inline bool f29_enabled() {
     const char* e = getenv("ZK_MSM_F29");   // "0" forces the saturated 32-bit path (A/B measurements, tests)

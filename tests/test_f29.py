@@ -12,8 +12,15 @@ from oracle import pyref
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "emu", "f29_check")
-W, MASK = 29, (1 << 29) - 1
-FIELDS = ["PallasFp", "PallasFq", "Bn254Fq"]
+FIELDS = ["PallasFp", "PallasFq", "Bn254Fq", "Bls381Fq"]
+SHAPE = {"PallasFp": (29, 9, 8), "PallasFq": (29, 9, 8), "Bn254Fq": (29, 9, 8), "Bls381Fq": (28, 14, 12)}   # W, L, 32-bit words
+W = L = MASK = NW = None
+
+
+def shape(field):
+    global W, L, MASK, NW
+    W, L, NW = SHAPE[field]
+    MASK = (1 << W) - 1
 
 
 def build():
@@ -29,18 +36,18 @@ def val(limbs):
 
 
 def limbs_of(x, strict_top=False):
-    out = [(x >> (W * i)) & MASK for i in range(8)]
-    out.append(x >> (W * 8))
+    out = [(x >> (W * i)) & MASK for i in range(L - 1)]
+    out.append(x >> (W * (L - 1)))
     return out
 
 
 def spread_random(rng, x, lb):
     """random lazy representation of integer x with limbs below the top in [0, lb]"""
     out = limbs_of(x)
-    for i in range(8):
-        # move a multiple of 2^29 from limb i+1 into limb i when possible
+    for i in range(L - 1):
+        # move a multiple of 2^W from limb i+1 into limb i when possible
         room = (lb - out[i]) >> W
-        take = min(room, out[i + 1]) if i + 1 < 9 else 0
+        take = min(room, out[i + 1])
         if take > 0:
             t = rng.randint(0, take)
             out[i] += t << W
@@ -64,44 +71,49 @@ def test_bound_checker():
 
 @pytest.mark.parametrize("field", FIELDS)
 def test_f29_mul_extremes(field):
+    shape(field)
     p = pyref.FIELDS[field][0]
-    Rp = 1 << 261
+    Rp = 1 << (W * L)
+    top = p >> (W * (L - 1))
     rng = random.Random(29)
     cases = []
-    max_n = [(1 << 29) + 6] * 8          # N+ limbs at their maximum
-    max_s = [int(2 ** 31.2)] * 8          # the widest subtrahend form a product ever sees
+    nplus = MASK + (1 << (32 - W)) - 1
+    wide = MASK + 1 + 2 * (MASK + 1) + nplus                 # q - x3 + BIAS16K2: the widest form a product ever sees
+    max_n = [nplus] * (L - 1)                # N+ limbs at their maximum
+    max_s = [wide] * (L - 1)
     for k in range(200):
         if k == 0:
-            a, b = max_n + [18 << 22], max_s + [17 << 22]
+            a, b = max_n + [18 * top], max_s + [17 * top]
         elif k == 1:
-            a, b = [(1 << 30) + 12] * 8 + [16 << 22], [(1 << 30) + 12] * 8 + [16 << 22]   # u = 2y squared in dbl
+            a, b = [2 * nplus] * (L - 1) + [16 * top], [2 * nplus] * (L - 1) + [16 * top]   # u = 2y squared in dbl
         elif k == 2:
-            a, b = [0] * 9, max_s + [1]
+            a, b = [0] * L, max_s + [1]
         elif k < 100:
-            a = spread_random(rng, rng.randrange(18 * p), (1 << 29) + 6)
-            b = spread_random(rng, rng.randrange(17 * p), int(2 ** 31.2))
+            a = spread_random(rng, rng.randrange(18 * p), nplus)
+            b = spread_random(rng, rng.randrange(17 * p), wide)
         else:
             a, b = limbs_of(rng.randrange(2 * p)), limbs_of(rng.randrange(2 * p))
         cases.append((a, b))
     res = run([(field, "mul", a, b) for a, b in cases])
     for (a, b), r in zip(cases, res):
-        assert all(x <= MASK for x in r[:8])                                   # strict limbs
+        assert all(x <= MASK for x in r[:L - 1])                               # strict limbs
         assert val(r) * Rp % p == val(a) * val(b) % p                          # Montgomery relation
         assert val(r) < val(a) * val(b) // Rp + p + 1                          # value bound
 
 
 @pytest.mark.parametrize("field", FIELDS)
 def test_f29_sub_norm_canon(field):
+    shape(field)
     p = pyref.FIELDS[field][0]
     rng = random.Random(7)
+    nplus = MASK + (1 << (32 - W)) - 1
     lines, exp = [], []
     for k in range(100):
         a = spread_random(rng, rng.randrange(2 * p), MASK)
-        b12 = spread_random(rng, rng.randrange(12 * p), (1 << 29) + 6)
+        b12 = spread_random(rng, rng.randrange(12 * p), nplus)
         b2 = limbs_of(rng.randrange(2 * p))
         if k == 0:
-            a, b12 = [0] * 9, limbs_of(12 * p - 1)
-            b12 = [(1 << 29) + 6 if i < 8 else b12[8] - 1 for i in range(9)] if False else b12
+            a, b12 = [0] * L, limbs_of(12 * p - 1)
         lines.append((field, "sub16k2", a, b12)); exp.append(val(a) - val(b12) + 16 * p)
         lines.append((field, "sub4k1", a, b2)); exp.append(val(a) - val(b2) + 4 * p)
         lines.append((field, "sub3", a, b2)); exp.append(val(a) - 3 * val(b2) + 8 * p)
@@ -113,46 +125,47 @@ def test_f29_sub_norm_canon(field):
     lines, chk = [], []
     for k in range(100):
         x = rng.randrange(19 * p)
-        lazy = spread_random(rng, x, (1 << 32) - 1 - (7 << 29)) if k else [0xFFFFFFF0] * 8 + [1]   # carry-in <= 7 must not wrap a word
+        lazy = spread_random(rng, x, (1 << 32) - 1 - (((1 << (32 - W)) - 1) << W)) if k else [0xFFFFFFF0] * (L - 1) + [1]   # carry-in must not wrap a word
         x = val(lazy)
         if x >= 20 * p:
             continue
-        lines.append((field, "norm", lazy, [0] * 9)); chk.append(("norm", x))
-        lines.append((field, "carry", lazy, [0] * 9)); chk.append(("carry", x))
-        lines.append((field, "canon", lazy, [0] * 9)); chk.append(("canon", x))
+        lines.append((field, "norm", lazy, [0] * L)); chk.append(("norm", x))
+        lines.append((field, "carry", lazy, [0] * L)); chk.append(("carry", x))
+        lines.append((field, "canon", lazy, [0] * L)); chk.append(("canon", x))
     res = run(lines)
     for r, (op, x) in zip(res, chk):
         if op == "norm":
-            assert val(r) == x and all(v <= (1 << 29) + 6 for v in r[:8])
+            assert val(r) == x and all(v <= MASK + (1 << (32 - W)) - 1 for v in r[:L - 1])
         elif op == "carry":
-            assert val(r) == x and all(v <= MASK for v in r[:8])
+            assert val(r) == x and all(v <= MASK for v in r[:L - 1])
         else:
-            assert val(r) == x % p and all(v <= MASK for v in r[:8])
+            assert val(r) == x % p and all(v <= MASK for v in r[:L - 1])
 
 
 @pytest.mark.parametrize("field", FIELDS)
 def test_f29_conversion_and_zero_filter(field):
+    shape(field)
     p = pyref.FIELDS[field][0]
     rng = random.Random(3)
-    R, Rp = 1 << 256, 1 << 261
+    R, Rp = 1 << (32 * NW), 1 << (W * L)
     lines, xs = [], []
     for k in range(50):
         x = [0, 1, p - 1][k] if k < 3 else rng.randrange(p)
         std = x * R % p
-        words = [(std >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [0]
-        lines.append((field, "fromstd", words, [0] * 9)); xs.append(x)
+        words = [(std >> (32 * i)) & 0xFFFFFFFF for i in range(NW)] + [0] * (L - NW)
+        lines.append((field, "fromstd", words, [0] * L)); xs.append(x)
     res = run(lines)
     back = []
     for r, x in zip(res, xs):
-        assert val(r) % p == x * Rp % p and val(r) < 2 * p and all(v <= MASK for v in r[:8])
+        assert val(r) % p == x * Rp % p and val(r) < 2 * p and all(v <= MASK for v in r[:L - 1])
         if x == 0:
             assert val(r) == 0
         # lazy variant of the same value goes back to the canonical standard form
         lazy = spread_random(rng, val(r) + rng.randrange(10) * p, (1 << 31))
-        back.append((field, "tostd", lazy, [0] * 9))
+        back.append((field, "tostd", lazy, [0] * L))
     res = run(back)
     for r, x in zip(res, xs):
-        got = sum(w << (32 * i) for i, w in enumerate(r[:8]))
+        got = sum(w << (32 * i) for i, w in enumerate(r[:NW]))
         assert got == x * R % p
     # zero filter: multiples of p in range are accepted exactly, everything else rejected
     lines, exp = [], []
@@ -160,10 +173,10 @@ def test_f29_conversion_and_zero_filter(field):
         for delta in (0, 1, p // 3):
             x = k * p + delta
             lazy = spread_random(rng, x, 1 << 31)
-            lines.append((field, "filter", lazy, [3, 17] + [0] * 7)); exp.append(delta == 0)
+            lines.append((field, "filter", lazy, [3, 17] + [0] * (L - 2))); exp.append(delta == 0)
     for _ in range(200):
         x = rng.randrange(3 * p, 18 * p)
-        lines.append((field, "filter", spread_random(rng, x, 1 << 31), [3, 17] + [0] * 7)); exp.append(x % p == 0)
+        lines.append((field, "filter", spread_random(rng, x, 1 << 31), [3, 17] + [0] * (L - 2))); exp.append(x % p == 0)
     res = run(lines)
     for r, e in zip(res, exp):
         assert bool(r[2]) == e

@@ -9,10 +9,17 @@ mirror the C++ one to one and assert what the C++ relies on:
 Run: python tools/check_f29_bounds.py   (also executed by tests/test_f29_bounds.py)."""
 import sys
 
-W = 29
-STRICT = (1 << W) - 1
-NPLUS = STRICT + 7
-P_OVER_R = 2.0 ** -7 * 1.0000001      # p / 2^261 for p < 2^254 (1 + 2^-100)
+# set per shape by configure(): 9 x 29 bits (254/255-bit fields) or 14 x 28 bits (BLS12-381 Fq)
+W = L = STRICT = NPLUS = P_OVER_R = TOP_UNIT = None
+
+
+def configure(w, l, log2p_max, log2p_min):
+    global W, L, STRICT, NPLUS, P_OVER_R, TOP_UNIT
+    W, L = w, l
+    STRICT = (1 << W) - 1
+    NPLUS = STRICT + ((1 << (32 - W)) - 1)
+    P_OVER_R = 2.0 ** (log2p_max - W * L)                      # upper bound of p / R'
+    TOP_UNIT = int(2.0 ** (log2p_min - W * (L - 1)))           # lower bound of p >> (W (L-1)): the top limb of one p
 
 
 class V:
@@ -24,7 +31,7 @@ class V:
 
 
 def mul(a, b, name="mul"):
-    col = 9 * a.lb * b.lb + 9 * (1 << 58) + (1 << 36)
+    col = L * a.lb * b.lb + L * (1 << (2 * W)) + (1 << (64 - W + 1))
     assert col < 1 << 64, ("column overflow", name, a, b)
     r = V(STRICT, a.vb * b.vb * P_OVER_R + 1.0, name)
     assert r.vb < 20, ("value too large for KP table / top limb", name, r)
@@ -47,7 +54,7 @@ def sub(a, subtrahends, bias, name="sub"):
     # every bias limb below the top is >= k * 2^29 - k
     assert tot_lb <= k * (1 << W) - k, ("limb could go negative", name, tot_lb, k)
     # top limb: bias_8 = floor(mult p / 2^232) - k >= total top limbs of the subtrahends  <=  (mult - tot_vb) p / 2^232 >= k + 1
-    assert (mult - tot_vb) * (1 << 21) >= k + 1, ("top limb could go negative", name, mult, tot_vb)
+    assert (mult - tot_vb) * TOP_UNIT >= k + 1, ("top limb could go negative", name, mult, tot_vb)
     max_bias_limb = (1 << W) - 1 + k * (1 << W)
     r = V(a.lb + max_bias_limb, a.vb + mult, name)
     assert r.lb < 1 << 32, ("u32 overflow", name, r)
@@ -65,7 +72,9 @@ def stored(x, y, zz, zzz):
     assert zz.lb <= STRICT and zz.vb < 2 and zzz.lb <= STRICT and zzz.vb < 2
 
 
-def main():
+def check_shape(w, l, log2p_max, log2p_min):
+    configure(w, l, log2p_max, log2p_min)
+    print("== %d x %d-bit limbs, 2^%.2f < p < 2^%.2f" % (l, w, log2p_min, log2p_max))
     X1, Y1, ZZ1, ZZZ1 = V(NPLUS, 12, "X1"), V(NPLUS, 8, "Y1"), V(STRICT, 2, "ZZ1"), V(STRICT, 2, "ZZZ1")
     qx, qy = V(STRICT, 2, "qx"), V(NPLUS, 4, "qy")     # converted base; y possibly negated
 
@@ -129,6 +138,11 @@ def main():
     # ---- conversion back: norm, multiply by FROM29 (strict, < p), canon handles < 20 p
     for c in (X1, Y1, ZZ1):
         assert mul(norm(c), V(STRICT, 1)).vb < 2
+
+
+def main():
+    check_shape(29, 9, 254.001, 253.5)     # Pasta Fp / Fq (p = 2^254 (1 + 2^-128)), BN254 Fq (2^253.6)
+    check_shape(28, 14, 380.8, 380.6)      # BLS12-381 Fq (2^380.7)
     print("all F29 bounds hold")
     return 0
 
