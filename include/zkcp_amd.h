@@ -79,7 +79,7 @@ typedef struct {
     float digits_ms, hist_ms, scatter_ms, accumulate_ms, reduce_ms, host_tail_ms, total_ms;
     int window_bits, windows_total, windows_done;
     int groups;      /* window groups pipelined on two streams (phase times above are summed over groups, total_ms is wall) */
-    int limb_bits;   /* bucket arithmetic of the call: 32 = saturated words, 29 = lazy 9 x 29-bit limbs (8-word G1 curves) */
+    int limb_bits;   /* bucket arithmetic of the call: 32 = saturated words (G2), 29 = lazy unsaturated limbs (G1: 9 x 29 bits, BLS12-381 14 x 28) */
 } zk_msm_profile;
 
 /* ---- lifecycle ---- */

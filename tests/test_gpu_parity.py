@@ -162,3 +162,37 @@ def test_msm_full_size_2p20(zk, cname):
     tot2 = sum(a * b for a, b in zip(orc.array_to_ints(sc2), orc.array_to_ints(ks))) % r
     assert (got2 == orc.scalar_mul(cname, orc.curve_generator(cname), orc.int_to_limbs(tot2, 4))).all()
     bases.free()
+
+
+def test_msm_2p22_bn254(zk):
+    """BASELINE configs[3] scale: 2^22-point BN254 G1 MSM (Groth16-sized), structural identity + the threaded oracle."""
+    import torch
+    from oracle import pyref
+    cname, n = "Bn254G1", 1 << 22
+    ks, d_pts = _device_bases(zk, cname, n)
+    sc = ps.scalars_for(cname, n, 321)
+    bases = zk.Bases(cname, device_tensor=d_pts, n=n)
+    got = zk.point_to_affine(cname, zk.msm(bases, torch.from_numpy(sc.view(np.int64)).cuda()))
+    assert zk.msm_last_profile()["limb_bits"] == 29
+    r = pyref.FIELDS[pyref.CURVES[cname][1]][0]
+    tot = sum(a * b for a, b in zip(orc.array_to_ints(sc), orc.array_to_ints(ks))) % r
+    assert (got == orc.scalar_mul(cname, orc.curve_generator(cname), orc.int_to_limbs(tot, 4))).all()
+    pts = d_pts.cpu().numpy().view(np.uint64)
+    assert (got == orc.msm_ark(cname, pts, sc, threads=min(32, os.cpu_count() or 8))).all()
+    bases.free()
+
+
+def test_msm_full_size_bls12_381(zk):
+    """the reference's curve (lib/src/lib.rs:21-24) at the domain size of its largest test (2^20): G1 on 14 x 28-bit lazy limbs"""
+    import torch
+    from oracle import pyref
+    cname, n = "Bls381G1", 1 << 20
+    ks, d_pts = _device_bases(zk, cname, n)
+    sc = ps.scalars_for(cname, n, 654, realistic=True)
+    bases = zk.Bases(cname, device_tensor=d_pts, n=n)
+    got = zk.point_to_affine(cname, zk.msm(bases, torch.from_numpy(sc.view(np.int64)).cuda()))
+    assert zk.msm_last_profile()["limb_bits"] == 29
+    r = pyref.FIELDS[pyref.CURVES[cname][1]][0]
+    tot = sum(a * b for a, b in zip(orc.array_to_ints(sc), orc.array_to_ints(ks))) % r
+    assert (got == orc.scalar_mul(cname, orc.curve_generator(cname), orc.int_to_limbs(tot, 4))).all()
+    bases.free()
