@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--realistic", action="store_true", help="0/1-heavy witness mix (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="column", choices=["column", "halo2"],
+                    help="column: BASELINE configs[1] (default, the headline). halo2: the synthetic 2^20-row halo2 GPU work-list "
+                         "of SURVEY 8d / configs[2]: 13 advice commits (MSM) + 13 iNTT(2^k) + 13 extended NTT(2^(k+3)) + 1 extended iNTT")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,6 +85,9 @@ def main():
                 "hist_ms": 0.0, "host_tail_ms": 0.0}
     ntt_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     result = {}
+
+    if args.workload == "halo2":
+        return bench_halo2(args, zk, zkdist, ps, torch, dist, np, curve, sfield, n, bases, d_sc, d_a, world, rank, st)
 
     def step(i, timed):
         if i % world == rank:
@@ -140,7 +146,8 @@ def main():
         line = {
             "metric": "constraints/sec", "value": value, "unit": "constraints/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u32x8 (256-bit Montgomery integers)" if nl == 4 else "u32x12 (384-bit Montgomery integers)",
+            "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery integers; MSM buckets on 9 x 29-bit lazy limbs, NTT on 8 x 32)" if nl == 4
+                     else "u32 limbs (384-bit Montgomery integers; MSM buckets on 14 x 28-bit lazy limbs)",
             "data": "synthetic",
             "config": {"workload": "2^%d-point %s MSM + 2^%d %s NTT per step (BASELINE configs[1])" % (args.logn, curve, args.logn, sfield),
                        "rows_per_step": n, "scalars": "realistic-0/1-mix" if args.realistic else "uniform",
@@ -153,15 +160,79 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "note": "integer-ALU-bound by construction (SURVEY 8d); see int_mad_roofline"},
         }
-        # second roofline: 32x32->64 MADs actually needed vs the measured v_mad_u64_u32 peak (tools/microbench)
-        mads_per_mul = {"PallasFp": 88, "PallasFq": 88}.get(pyref.CURVES[curve][0], 2 * (2 * nl) ** 2)
+        # second roofline: the 32x32->64 MADs a mixed add strictly needs vs the measured v_mad_u64_u32 peak
+        # (tools/microbench).  MADs per Montgomery product: a*b plus m*p over the non-zero modulus limbs, in the limb form the
+        # call ran in (lazy 9 x 29 / 14 x 28-bit limbs, or saturated 32-bit words).
+        base_field = pyref.CURVES[curve][0]
+        lazy = prof["limb_bits"] == 29
+        mads_per_mul = ({"PallasFp": 135, "PallasFq": 135, "Bn254Fq": 162, "Bls381Fq": 392} if lazy else
+                        {"PallasFp": 104, "PallasFq": 104, "Bn254Fq": 128, "Bls381Fq": 288})[base_field] * (3 if "G2" in curve else 1)
         adds = n * prof["windows_done"]
         line["int_mad_roofline"] = {"achieved_tmad_s": adds * 10 * mads_per_mul / (acc_ms * 1e-3) / 1e12, "peak_tmad_s": 33.7,
+                                    "mads_per_field_mul": mads_per_mul, "limb_bits": prof["limb_bits"],
                                     "note": "mixed adds x 10 field mul x MADs/mul over accumulate time; peak = measured v_mad_u64_u32 rate"}
         line["int_mad_roofline"]["frac"] = line["int_mad_roofline"]["achieved_tmad_s"] / 33.7
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(curve, sfield, args.logn, d_pts, sc_host, a_host, omega, result["msm"], zk)
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_halo2(args, zk, zkdist, ps, torch, dist, np, curve, sfield, n, bases, d_col, d_a, world, rank, st):
+    """Synthetic halo2 prover work-list for one 2^k-row circuit with the column layout of the reference's ElGamalGadget
+    (13 advice columns, circuits-halo2/src/encryption.rs:83-161; SURVEY 8a a11, 8d 'Config 3'): per advice column one
+    commitment MSM over the Lagrange column, lagrange_to_coeff (iNTT 2^k), coeff_to_extended (zeta-coset shift + NTT on the
+    extended domain 2^(k+3)); then one extended_to_coeff for the quotient.  IPA opening, permutation / lookup products and
+    the transcript stay on the CPU (SURVEY 8f f4) and are not part of this line.  MSMs are window-sharded over the ranks;
+    every NTT is single-GPU, columns are dealt round-robin."""
+    k, ext = args.logn, args.logn + 3
+    ncol = 13
+    omega, omega_ext = zk.root_of_unity(sfield, k), zk.root_of_unity(sfield, ext)
+    omega_inv, omega_ext_inv = zk.field_inverse(sfield, omega), zk.field_inverse(sfield, omega_ext)
+    zeta = zk.multiplicative_generator(sfield)          # stands in for halo2's ZETA coset shift (any fixed non-trivial shift)
+    zeta_inv = zk.field_inverse(sfield, zeta)
+    d_ext = torch.zeros((1 << ext, 4), dtype=torch.int64, device="cuda")
+    d_work = torch.empty_like(d_a)
+
+    def step():
+        for c in range(ncol):
+            zkdist.msm_sharded(bases, d_col, montgomery=True, window_bits=args.window_bits, stream=st)   # commit(advice column)
+            if c % world == rank:
+                d_work.copy_(d_a)
+                zk.ntt(sfield, d_work, omega_inv, scale_by_n_inv=True, stream=st)                         # lagrange_to_coeff
+                d_ext.zero_()
+                d_ext[:n].copy_(d_work)
+                zk.ntt(sfield, d_ext, omega_ext, stream=st, coset_pre=zeta)                               # coeff_to_extended (zeta shift fused)
+        if rank == 0:
+            zk.ntt(sfield, d_ext, omega_ext_inv, scale_by_n_inv=True, stream=st, coset_post=zeta_inv)     # extended_to_coeff (quotient)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "constraints/sec", "value": n * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery integers)", "data": "synthetic",
+            "config": {"workload": "synthetic halo2 GPU work-list, 2^%d rows: 13 x (%s MSM + iNTT 2^%d + coset NTT 2^%d) + 1 iNTT 2^%d"
+                                   % (k, curve, k, ext, ext), "rows_per_step": n, "parallelism": "msm-window-shard x%d" % world}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -58,9 +58,11 @@ class Radix2EvaluationDomain:
         return ntt(self.field, a, self.group_gen_inv, scale_by_n_inv=True)
 
     def coset_fft_in_place(self, a):
+        """distribute_powers(generator) ; fft  -- one fused launch sequence on device buffers"""
         self._check(a)
-        return ntt(self.field, coset_mul(self.field, a, self.generator), self.group_gen)
+        return ntt(self.field, a, self.group_gen, coset_pre=self.generator)
 
     def coset_ifft_in_place(self, a):
+        """ifft ; distribute_powers(generator^-1)"""
         self._check(a)
-        return coset_mul(self.field, ntt(self.field, a, self.group_gen_inv, scale_by_n_inv=True), self.generator_inv)
+        return ntt(self.field, a, self.group_gen_inv, scale_by_n_inv=True, coset_post=self.generator_inv)

@@ -245,6 +245,20 @@ API int zk_ntt(zk_field_t f, void* a_host, uint32_t log_n, const void* omega, in
     HIP_TRY(hipMemcpy(a_host, g.scratch_in.p, bytes, hipMemcpyDeviceToHost));
     return ZK_OK;
 }
+API int zk_ntt_coset_device(zk_field_t f, void* a, uint32_t log_n, const void* omega, int scale, const void* g_pre,
+                            const void* g_post, void* stream) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    ZK_TRY(require_init());
+    if (!a || !omega || !aligned16(a)) return ZK_ERR_INVALID_ARG;
+    FIELD_SWITCH(f, {
+        Fe<F> w, gp, gq;
+        host_load(w, omega);
+        if (g_pre) host_load(gp, g_pre);
+        if (g_post) host_load(gq, g_post);
+        return ntt_run<F>((int)f, (Fe<F>*)a, log_n, w, scale, (hipStream_t)stream, g_pre ? &gp : nullptr, g_post ? &gq : nullptr);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
 API int zk_coset_mul_device(zk_field_t f, void* a, uint32_t log_n, const void* gm, void* stream) {
     std::lock_guard<std::mutex> lk(g.mu);
     ZK_TRY(require_init());
@@ -252,7 +266,7 @@ API int zk_coset_mul_device(zk_field_t f, void* a, uint32_t log_n, const void* g
     FIELD_SWITCH(f, {
         Fe<F> w;
         host_load(w, gm);
-        return coset_run<F>((Fe<F>*)a, log_n, w, (hipStream_t)stream);
+        return coset_run<F>((int)f, (Fe<F>*)a, log_n, w, (hipStream_t)stream);
     });
     return ZK_ERR_INVALID_ARG;
 }
@@ -266,7 +280,7 @@ API int zk_coset_mul(zk_field_t f, void* a_host, uint32_t log_n, const void* gm)
     FIELD_SWITCH(f, {
         Fe<F> w;
         host_load(w, gm);
-        ZK_TRY(coset_run<F>((Fe<F>*)g.scratch_in.p, log_n, w, (hipStream_t)0));
+        ZK_TRY(coset_run<F>((int)f, (Fe<F>*)g.scratch_in.p, log_n, w, (hipStream_t)0));
     });
     HIP_TRY(hipMemcpy(a_host, g.scratch_in.p, bytes, hipMemcpyDeviceToHost));
     return ZK_OK;

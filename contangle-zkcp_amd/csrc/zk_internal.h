@@ -132,9 +132,10 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 
 template <class F>
-int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st);
+int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st, const Fe<F>* g_pre = nullptr,
+            const Fe<F>* g_post = nullptr);
 template <class F>
-int coset_run(Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st);
+int coset_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st);
 template <class F>
 int vec_op_run(Fe<F>* a, const Fe<F>* b, const Fe<F>* c, uint64_t n, int op, const Fe<F>& s, hipStream_t st);
 template <class F>

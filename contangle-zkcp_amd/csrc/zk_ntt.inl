@@ -99,9 +99,65 @@ int tw_table(const Fe<F>& omega, uint32_t logn, int field, hipStream_t st, const
     return ZK_OK;
 }
 
+// device tables lo[j] = g^j (j < min(n,1024)), hi[j] = g^(1024 j) (j < max(1, n/1024)) for on-the-fly coset powers; cached
 template <class F>
-int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st) {
-    if (logn == 0) return ZK_OK;  // size-1 transform is the identity, and n^-1 = 1
+int pow_tables(const Fe<F>& gshift, uint32_t logn, int field, hipStream_t st, PowTables<F>* out) {
+    TwKey key;
+    memset(&key, 0, sizeof key);
+    key.field = field | 0x100;   // separate key space from the twiddle tables
+    key.logn = logn;
+    memcpy(key.omega, gshift.v, sizeof(uint32_t) * F::N);
+    auto it = g.tw.find(key);
+    const uint64_t nlo = logn >= 10 ? 1024 : (1ull << logn), nhi = logn > 10 ? (1ull << (logn - 10)) : 1;
+    if (it == g.tw.end()) {
+        while (g.tw.size() >= 16 || g.tw_bytes > (2ull << 30)) {
+            auto victim = g.tw.begin();
+            for (auto i2 = g.tw.begin(); i2 != g.tw.end(); ++i2)
+                if (i2->second.stamp < victim->second.stamp) victim = i2;
+            HIP_TRY(hipStreamSynchronize(st));
+            hipFree(victim->second.dev);
+            g.tw_bytes -= victim->second.bytes;
+            g.tw.erase(victim);
+        }
+        // 2^k power ladders of g (10 entries) and of g^1024 (logn - 10 entries), then two table kernels
+        std::vector<Fe<F>> lad(64);
+        Fe<F> w = gshift;
+        for (int k = 0; k < 10; k++) {
+            lad[k] = w;
+            fe_sqr(w, w);
+        }
+        for (int k = 0; k < 22; k++) {   // w = g^1024 here
+            lad[32 + k] = w;
+            fe_sqr(w, w);
+        }
+        void* dev = nullptr;
+        const size_t bytes = sizeof(Fe<F>) * (nlo + nhi + 64);
+        HIP_TRY(hipMalloc(&dev, bytes));
+        Fe<F>* d_lad = (Fe<F>*)dev + nlo + nhi;
+        HIP_TRY(hipMemcpyAsync(d_lad, lad.data(), sizeof(Fe<F>) * 64, hipMemcpyHostToDevice, st));
+        ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nlo + 255) / 256), 256, 0, st, (Fe<F>*)dev, (const Fe<F>*)d_lad, nlo, 10);
+        ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nhi + 255) / 256), 256, 0, st, (Fe<F>*)dev + nlo, (const Fe<F>*)(d_lad + 32), nhi, 22);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));   // `lad` is a host temporary
+        TwEntry e{dev, bytes, ++g.tw_stamp};
+        g.tw[key] = e;
+        g.tw_bytes += bytes;
+        it = g.tw.find(key);
+    }
+    it->second.stamp = ++g.tw_stamp;
+    out->lo = (const Fe<F>*)it->second.dev;
+    out->hi = (const Fe<F>*)it->second.dev + nlo;
+    return ZK_OK;
+}
+
+// size-2^logn DFT of `a` with root omega; optionally fused with a[i] *= g_pre^i before and a[k] *= g_post^k after
+template <class F>
+int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st, const Fe<F>* g_pre,
+            const Fe<F>* g_post) {
+    if (logn == 0) return ZK_OK;  // size-1 transform is the identity, n^-1 = 1 and g^0 = 1
+    PowTables<F> tpre{nullptr, nullptr}, tpost{nullptr, nullptr};
+    if (g_pre) ZK_TRY(pow_tables<F>(*g_pre, logn, field, st, &tpre));
+    if (g_post) ZK_TRY(pow_tables<F>(*g_post, logn, field, st, &tpost));
     if (logn > (uint32_t)F::TWO_ADICITY || logn > 30) return ZK_ERR_INVALID_ARG;
     const Fe<F>* tw = nullptr;
     ZK_TRY(tw_table<F>(omega, logn, field, st, &tw));
@@ -132,6 +188,8 @@ int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_fl
         A.scale = A.last ? scale_flag : 0;
         A.nd = plan.nd;
         for (int i = 0; i < plan.nd; i++) A.rd[i] = plan.rd[i];
+        A.pre = (p == 0 && g_pre) ? 1 : 0;
+        A.post = (A.last && g_post) ? 1 : 0;
         const Fe<F>* src;
         Fe<F>* dst;
         if (plan.nd == 1) {
@@ -159,7 +217,7 @@ int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_fl
         if (shmem > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        ZK_LAUNCH((ntt_pass_kernel<F>), (unsigned)tiles, blk, shmem, st, src, dst, tw, A, scale);
+        ZK_LAUNCH((ntt_pass_kernel<F>), (unsigned)tiles, blk, shmem, st, src, dst, tw, A, scale, tpre, tpost);
         HIP_TRY(hipGetLastError());
         log_m += plan.rd[p];
     }
@@ -167,25 +225,17 @@ int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_fl
 }
 
 template <class F>
-int coset_run(Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st) {
+int coset_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st) {
     if (logn > 30) return ZK_ERR_INVALID_ARG;
     const uint64_t count = 1ull << logn;
-    std::vector<Fe<F>> tbl(logn ? logn : 1);
-    Fe<F> w = gshift;
-    for (uint32_t k = 0; k < logn; k++) {
-        tbl[k] = w;
-        fe_sqr(w, w);
-    }
-    ZK_TRY(ws_get(g.pow_tbl, sizeof(Fe<F>) * 64));
-    HIP_TRY(hipMemcpyAsync(g.pow_tbl.p, tbl.data(), sizeof(Fe<F>) * tbl.size(), hipMemcpyHostToDevice, st));
-    const unsigned blk = 256;
-    ZK_LAUNCH((coset_mul_kernel<F>), (unsigned)((count + blk - 1) / blk), blk, 0, st, a, (const Fe<F>*)g.pow_tbl.p, count,
-              (int)logn);
+    PowTables<F> t;
+    ZK_TRY(pow_tables<F>(gshift, logn, field, st, &t));
+    uint64_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    ZK_LAUNCH((coset_mul_kernel<F>), (unsigned)blocks, 256, 0, st, a, t, count);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));  // pow_tbl reuse
     return ZK_OK;
 }
-
 
 template <class F>
 int vec_op_run(Fe<F>* a, const Fe<F>* b, const Fe<F>* c, uint64_t n, int op, const Fe<F>& s, hipStream_t st) {
@@ -221,13 +271,11 @@ int witness_map_run(int field, Fe<F>* a, Fe<F>* b, Fe<F>* c, uint32_t logm, hipS
     fe_inv(zinv, gm);
     Fe<F>* vs[3] = {a, b, c};
     for (int k = 0; k < 3; k++) {
-        ZK_TRY(ntt_run<F>(field, vs[k], logm, winv, 1, st));   // ifft_in_place
-        ZK_TRY(coset_run<F>(vs[k], logm, gen, st));            // distribute_powers(g)
-        ZK_TRY(ntt_run<F>(field, vs[k], logm, w, 0, st));      // fft_in_place
+        ZK_TRY(ntt_run<F>(field, vs[k], logm, winv, 1, st, nullptr, nullptr));   // ifft_in_place
+        ZK_TRY(ntt_run<F>(field, vs[k], logm, w, 0, st, &gen, nullptr));          // coset_fft = distribute_powers(g) ; fft (fused)
     }
     ZK_TRY(vec_op_run<F>(a, b, c, m, VEC_QAP, zinv, st));
-    ZK_TRY(ntt_run<F>(field, a, logm, winv, 1, st));           // coset_ifft = ifft ; distribute_powers(g^-1)
-    ZK_TRY(coset_run<F>(a, logm, ginv, st));
+    ZK_TRY(ntt_run<F>(field, a, logm, winv, 1, st, nullptr, &ginv));             // coset_ifft = ifft ; distribute_powers(g^-1) (fused)
     return ZK_OK;
 }
 }  // namespace zk

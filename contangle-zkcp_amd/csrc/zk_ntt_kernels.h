@@ -43,15 +43,27 @@ __global__ void pow_table_kernel(Fe<F>* __restrict__ out, const Fe<F>* __restric
     out[i] = acc;
 }
 
+// g^i on the fly from two small tables (1024 + n/1024 entries, L2 resident): lo[i & 1023] * hi[i >> 10]
+template <class F>
+struct PowTables {
+    const Fe<F>* lo;   // g^j,          j < min(n, 1024)
+    const Fe<F>* hi;   // (g^1024)^j,   j < max(1, n / 1024)
+};
+template <class F>
+__device__ __forceinline__ void mul_pow(Fe<F>& x, const PowTables<F>& t, uint64_t i) {
+    Fe<F> a = t.lo[i & 1023], b = t.hi[i >> 10];
+    fe_mul(x, x, a);
+    fe_mul(x, x, b);
+}
+
 // a[i] *= g^i   (ark-poly 0.3 Radix2EvaluationDomain::distribute_powers; halo2 coset shift by ZETA powers)
 template <class F>
-__global__ void coset_mul_kernel(Fe<F>* __restrict__ a, const Fe<F>* __restrict__ tbl, uint64_t count, int nbits) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    Fe<F> acc, x = a[i];
-    pow_from_table(acc, tbl, i, nbits);
-    fe_mul(x, x, acc);
-    a[i] = x;
+__global__ void __launch_bounds__(256) coset_mul_kernel(Fe<F>* __restrict__ a, PowTables<F> t, uint64_t count) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<F> x = a[i];
+        mul_pow(x, t, i);
+        a[i] = x;
+    }
 }
 
 // Pointwise vector kernels: the glue of ark-groth16 0.3 r1cs_to_qap.rs `witness_map` between its seven NTTs
@@ -118,6 +130,8 @@ struct NttPass {
     int scale;  // multiply outputs by `scale` (n^-1 for inverse transforms)
     int nd;     // P
     int rd[4];  // r_1..r_P
+    int pre;    // first pass multiplies input element i by g_pre^i on load   (ark coset_fft = distribute_powers ; fft)
+    int post;   // last pass multiplies output element k by g_post^k on store (ark coset_ifft = ifft ; distribute_powers)
 };
 
 template <class F>
@@ -133,7 +147,7 @@ __device__ __forceinline__ void tw_get(Fe<F>& w, const Fe<F>* __restrict__ tw, u
 
 template <class F>
 __global__ void __launch_bounds__(1024) ntt_pass_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out, const Fe<F>* __restrict__ tw,
-                                NttPass A, Fe<F> scale) {
+                                NttPass A, Fe<F> scale, PowTables<F> pre, PowTables<F> post) {
     ZK_DYN_SHARED(uint32_t, lds);
     constexpr int NL = F::N;
     const uint32_t R = 1u << A.log_r, T = 1u << A.log_t, RT = R * T;
@@ -185,7 +199,9 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(const Fe<F>* __restrict_
             t = e & (T - 1);
             j = e >> A.log_t;
         }
-        Fe<F> x = in[base + j * stride_j + t * stride_t];
+        const uint64_t gi = base + j * stride_j + t * stride_t;
+        Fe<F> x = in[gi];
+        if (A.pre) mul_pow(x, pre, gi);
         const uint32_t p = pos(j, t);
         ZK_UNROLL
         for (int l = 0; l < NL; l++) lds[l * RT + p] = x.v[l];
@@ -246,8 +262,10 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(const Fe<F>* __restrict_
             }
             out[base + (uint64_t)k * stride_j + t] = x;
         } else {
+            const uint64_t go = out_fixed + t + ((uint64_t)k << A.log_m);
             if (A.scale) fe_mul(x, x, scale);
-            out[out_fixed + t + ((uint64_t)k << A.log_m)] = x;
+            if (A.post) mul_pow(x, post, go);
+            out[go] = x;
         }
     }
 }

@@ -118,6 +118,15 @@ int zk_ntt(zk_field_t f, void *a_mont_host, uint32_t log_n, const void *omega_mo
 int zk_ntt_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *omega_mont_host,
                   int scale_by_n_inv, void *hip_stream);
 
+/* The NTT fused with the coset shifts around it (either pointer may be NULL):
+ *   a[i] *= g_pre^i  ->  DFT (root omega, optional 1/n scaling)  ->  a[k] *= g_post^k
+ * ark-poly 0.3: coset_fft_in_place  = (g_pre = F::multiplicative_generator(), omega = group_gen);
+ *               coset_ifft_in_place = (omega = group_gen_inv, scale = 1, g_post = generator^-1).
+ * halo2 0.2:    EvaluationDomain::coeff_to_extended / extended_to_coeff (zeta shifts around best_fft).
+ * The powers are formed on the fly from two small cached tables (g^j, j < 1024; g^(1024 j)), not read from an n-entry table. */
+int zk_ntt_coset_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *omega_mont_host, int scale_by_n_inv,
+                        const void *g_pre_mont_host, const void *g_post_mont_host, void *hip_stream);
+
 /* a[i] *= g^i, i < 2^log_n */
 int zk_coset_mul(zk_field_t f, void *a_mont_host, uint32_t log_n, const void *g_mont_host);
 int zk_coset_mul_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *g_mont_host, void *hip_stream);

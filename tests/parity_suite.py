@@ -320,3 +320,26 @@ def check_msm_groups(zk, cname, n, window_bits):
     finally:
         os.environ.pop("ZK_MSM_GROUPS", None)
     bases.free()
+
+
+def check_ntt_fused_coset(zk, name, logn, threads=8):
+    """zk_ntt_coset_device: the coset shifts fused into the first / last NTT pass (on-the-fly powers from two small
+    tables) against the oracle's ark-poly coset_fft / coset_ifft restatement."""
+    a = rand_field(name, 1 << logn, 17)
+    w = orc.root_of_unity(name, logn)
+    g = orc.field_generator(name)
+    winv, ginv = orc.fe_op(name, "inv", w), orc.fe_op(name, "inv", g)
+    d = to_device(zk, a)
+    got = to_host(zk, zk.ntt(name, d, w, coset_pre=g, device=True))
+    assert (got == orc.ark_fft(name, a, "coset_fft", threads=threads)).all(), (name, logn, "coset_fft")
+    d = to_device(zk, a)
+    got = to_host(zk, zk.ntt(name, d, winv, scale_by_n_inv=True, coset_post=ginv, device=True))
+    assert (got == orc.ark_fft(name, a, "coset_ifft", threads=threads)).all(), (name, logn, "coset_ifft")
+    # both at once: x -> g^-k/n DFT^-1 ( g^i x )  has no upstream name, check it against the two oracle steps
+    d = to_device(zk, a)
+    got = to_host(zk, zk.ntt(name, d, w, coset_pre=g, coset_post=ginv, device=True))
+    exp = orc.distribute_powers(name, orc.ark_fft(name, a, "coset_fft", threads=threads), ginv)
+    assert (got == exp).all()
+    # standalone coset_mul on a device buffer
+    d = to_device(zk, a)
+    assert (to_host(zk, zk.coset_mul(name, d, g)) == orc.distribute_powers(name, a, g)).all()

@@ -82,3 +82,10 @@ def test_vec_ops_and_witness_map(zk):
 def test_msm_window_groups(zk):
     ps.check_msm_groups(zk, "Vesta", 200, 5)
     ps.check_msm_groups(zk, "Bls381G1", 90, 7)
+
+
+def test_ntt_fused_coset(zk, monkeypatch):
+    for name, logn in (("Bls381Fr", 6), ("PallasFp", 11), ("Bn254Fr", 1), ("PallasFq", 12)):
+        ps.check_ntt_fused_coset(zk, name, logn)
+    monkeypatch.setenv("ZK_NTT_MAX_LOGR", "3")   # three passes: pre on the first, post on the last
+    ps.check_ntt_fused_coset(zk, "Bls381Fr", 8)

@@ -54,6 +54,11 @@ def test_ntt_full_size(zk, name, logn):
     ps.check_ntt_vs_oracle(zk, name, logn, threads=16)
 
 
+@pytest.mark.parametrize("name,logn", [("Bls381Fr", 9), ("PallasFp", 13), ("Bn254Fr", 16), ("PallasFq", 20), ("Bls381Fr", 22)])
+def test_ntt_fused_coset(zk, name, logn):
+    ps.check_ntt_fused_coset(zk, name, logn, threads=16)
+
+
 def test_ntt_device_tensor_path(zk):
     """torch-allocated HBM buffer + torch stream through zk_ntt_device (the bench path)."""
     import torch
