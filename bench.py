@@ -51,10 +51,18 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # ZK_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share devices; RCCL
+    # itself refuses two ranks on one GPU).  The driver's multi-GPU runs use the default: nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import contangle_zkcp_amd as zk
     from contangle_zkcp_amd import dist as zkdist
@@ -119,7 +127,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -223,7 +231,7 @@ def bench_halo2(args, zk, zkdist, ps, torch, dist, np, curve, sfield, n, bases, 
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:

@@ -52,8 +52,6 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         sh.rb = sh.nbk < 2048u ? sh.nbk : 2048u;
         sh.nranges = sh.nbk / sh.rb;
         sh.mont = mont;
-        sh.idx_mask = 0x7fffffffu;
-        if (const char* e = getenv("ZK_MSM_DEBUG_MASK")) sh.idx_mask = (uint32_t)strtoul(e, nullptr, 0);  // profiling only
         {   // oversize threshold: 2x the mean bucket length + 64 (uniform 2^20 / c=16: mean 32, max ~70 -> none)
             const uint64_t mean = n / sh.nbk;
             sh.big_thresh = (uint32_t)(2 * mean + 64);

@@ -40,7 +40,6 @@ struct MsmShape {
     uint32_t nranges; // ranges per window = nbk / rb
     int mont;         // scalars arrive in Montgomery form (halo2) rather than canonical (ark BigInt)
     uint32_t big_thresh;  // buckets longer than this take the cooperative path
-    uint32_t idx_mask;    // 0x7fffffff; narrowed only by the ZK_MSM_DEBUG_MASK profiling experiment (wrong results!)
 };
 
 template <int N>
@@ -304,7 +303,7 @@ __global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __r
         // ---- one mixed add for every lane that owns a bucket
         if (have) {
             const uint32_t e = sorted[pos];
-            Affine<C> p = bases[e & sh.idx_mask & 0x7fffffffu];
+            Affine<C> p = bases[e & 0x7fffffffu];
             aff_neg_if(p, (e >> 31) != 0);
             xyzz_add_mixed(acc, p);
             if (++pos == end) {
