@@ -96,7 +96,7 @@ def test_msm_edges(zk, cname):
 
 @pytest.mark.parametrize("cname", ps.CURVES)
 @pytest.mark.parametrize("n,wb,realistic", [(1000, 0, False), (4096, 0, True), (5000, 11, False), (1 << 14, 0, False),
-                                            (1 << 14, 13, True)])
+                                            (1 << 14, 13, True), (100003, 0, False)])
 def test_msm_vs_oracle(zk, cname, n, wb, realistic):
     ps.check_msm_vs_oracle(zk, cname, n, wb, realistic)
 
