@@ -75,7 +75,7 @@ struct Ctx {
     uint64_t tw_stamp = 0;
     size_t tw_bytes = 0;
     // workspaces (grow-only, reused across calls)
-    DevBuf ntt_tmp, pow_tbl, msm_counts, msm_digits, msm_queue, msm_seg_out, msm_sorted, msm_buckets, msm_part_a, msm_part_b, scratch_in, scratch_out;
+    DevBuf ntt_tmp, pow_tbl, msm_counts, msm_digits, msm_queue, msm_seg_out, msm_subacc, msm_sorted, msm_buckets, msm_part_a, msm_part_b, scratch_in, scratch_out;
     hipEvent_t ev[4 + 5 * 8];   // MSM phase events: 4 global + 5 per window group
     hipStream_t aux_stream = nullptr;
     bool have_events = false;

@@ -61,6 +61,25 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
             }
         }
         const int nw_all = sh.nw;
+        // Bucket splitting: with fewer than ~4 work items per resident lane the accumulate kernel ends in a long drain (every
+        // lane finishing one partly summed bucket) -- 2.7 buckets per lane for a full 2^20 MSM, less than one for the window
+        // share of a rank of a sharded MSM.  Cut every bucket into 2^split_log pieces (one extra point addition per piece).
+        // Measured at 2^20 / c = 16 (tools/shard_model.py, accumulate ms for split 0/1/2/3):
+        //   16 windows 1.49/1.32/1.36/1.59   8 windows 0.71/0.65/0.70/0.84   4 windows 0.55/0.42/0.39/0.49   2: 0.44/0.33/0.25/0.28
+        // i.e. halves while there are fewer than 8 buckets per lane, quarters below one bucket per lane, pieces never
+        // shorter than 8 entries on average.
+        {
+            const uint64_t lanes = (uint64_t)(g.num_cus > 0 ? g.num_cus : 256) * 4 * 3 * 64;
+            const uint64_t items = (uint64_t)nw_all * sh.nbk;
+            int sl = 0;
+            if (items < 8 * lanes && (n >> 1) / sh.nbk >= 8) sl = 1;
+            if (items < lanes && (n >> 2) / sh.nbk >= 8) sl = 2;
+            if (const char* e = getenv("ZK_MSM_SPLIT")) {
+                int v = atoi(e);
+                if (v >= 0 && v <= 4) sl = v;
+            }
+            sh.split_log = sl;
+        }
         // Window groups (experimental, default 1): the windows of the call can be cut into G groups issued alternately on two
         // HIP streams.  Measured on MI355X at 2^20 (tools/tune_msm.py): G = 2 / 4 is 1.5x / 2.7x SLOWER -- two persistent
         // accumulate kernels simply share the SIMDs, every group pays its own queue-drain tail, and the later groups' sort
@@ -84,7 +103,12 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         uint16_t* digits = (uint16_t*)g.msm_digits.p;
         ZK_TRY(ws_get(g.msm_sorted, (size_t)n * nw_all * 4));
         ZK_TRY(ws_get(g.msm_buckets, (size_t)nbuckets * sizeof(XYZZ<CK>)));
-        uint32_t L = 8;
+        if (sh.split_log > 0) ZK_TRY(ws_get(g.msm_subacc, ((size_t)nbuckets << sh.split_log) * sizeof(XYZZ<CK>)));
+        // slice length of the bucket reduction: keep ~64K lanes busy whatever the window share of this call (a rank of a
+        // window-sharded MSM owns few windows; shorter slices shorten the dependent chain, which is all this phase costs)
+        uint32_t L = (uint32_t)(((uint64_t)nw_all * sh.nbk) >> 16);
+        if (L < 1) L = 1;
+        if (L > 8) L = 8;
         if (const char* e = getenv("ZK_MSM_SLICE")) {
             int v = atoi(e);
             if (v >= 1 && v <= 1024) L = (uint32_t)v;
@@ -142,6 +166,7 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
             const uint16_t* digits_g = digits + (size_t)lw0 * sh.n_pad;
             uint32_t* sorted_g = (uint32_t*)g.msm_sorted.p + (size_t)lw0 * n;
             XYZZ<CK>* buckets_g = (XYZZ<CK>*)g.msm_buckets.p + (size_t)lw0 * sh.nbk;
+            XYZZ<CK>* acc_out_g = sh.split_log > 0 ? (XYZZ<CK>*)g.msm_subacc.p + (((size_t)lw0 * sh.nbk) << sh.split_log) : buckets_g;
             char* qbase = (char*)g.msm_queue.p + qstride_w * lw0;
             MsmQueue* q = (MsmQueue*)qbase;
             const size_t max_seg = max_seg_w * sg.nw;
@@ -162,11 +187,13 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
             // persistent accumulate: lanes stream buckets, largest first; oversized buckets go to the cooperative segment
             // kernels (fixed grids over device-side lists, no host round trip)
             HIP_TRY(hipMemsetAsync(q, 0, sizeof(MsmQueue), S));
-            const uint32_t ntasks = (nwg * ((sh.rb + 63) / 64) * 64 + MSM_BATCH - 1) / MSM_BATCH;  // batches in the queue
+            const uint32_t ntasks = (((nwg * ((sh.rb + 63) / 64) * 64) << sh.split_log) + MSM_BATCH - 1) / MSM_BATCH;  // batches in the queue
             unsigned acc_grid = (g.num_cus > 0 ? (unsigned)g.num_cus : 256u) * 4u * waves_per_simd;
             if (acc_grid > ntasks) acc_grid = ntasks;
             ZK_LAUNCH((msm_accumulate_kernel<CK>), acc_grid, 64, 0, S, bases, (const uint32_t*)sorted_g, (const uint32_t*)offs_g,
-                      (const uint32_t*)counts_g, (const uint32_t*)order_g, buckets_g, sg, q, seg_list, big_list);
+                      (const uint32_t*)counts_g, (const uint32_t*)order_g, acc_out_g, sg, q, seg_list, big_list);
+            if (sh.split_log > 0)
+                ZK_LAUNCH((msm_combine_sub_kernel<CK>), (nb_g + 63) / 64, 64, 0, S, (const XYZZ<CK>*)acc_out_g, buckets_g, nb_g, sh.split_log);
             const unsigned big_grid = max_seg < 4096 ? (unsigned)max_seg : 4096u;
             ZK_LAUNCH((msm_accumulate_big_kernel<CK>), big_grid, 64, 0, S, bases, (const uint32_t*)sorted_g, (const MsmQueue*)q,
                       (const MsmSeg*)seg_list, seg_out);

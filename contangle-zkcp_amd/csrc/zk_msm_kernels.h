@@ -40,6 +40,7 @@ struct MsmShape {
     uint32_t nranges; // ranges per window = nbk / rb
     int mont;         // scalars arrive in Montgomery form (halo2) rather than canonical (ark BigInt)
     uint32_t big_thresh;  // buckets longer than this take the cooperative path
+    int split_log;        // every bucket's entry list is cut into 2^split_log pieces summed by different lanes (msm_combine_sub_kernel adds them)
 };
 
 template <int N>
@@ -249,8 +250,9 @@ __global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __r
                                       MsmQueue* __restrict__ q, MsmSeg* __restrict__ seg_list, uint32_t* __restrict__ big_list) {
     __shared__ uint32_t s_next, s_end;
     const uint32_t nrt = (uint32_t)sh.nw * sh.nranges;                 // ranges in this call
-    const uint32_t per_rank = nrt * 64;                                // positions per size rank
-    const uint32_t total = ((sh.rb + 63) / 64) * per_rank;             // visiting positions (ranges padded to 64 slots)
+    const uint32_t per_rank = nrt * 64;                                // bucket positions per size rank
+    const uint32_t S = 1u << sh.split_log;                             // pieces per bucket
+    const uint32_t total = (((sh.rb + 63) / 64) * per_rank) << sh.split_log;   // visiting positions (ranges padded to 64 slots)
     const uint32_t lane = threadIdx.x;
     if (lane == 0) {
         s_next = 0;
@@ -258,41 +260,53 @@ __global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __r
     }
     __syncthreads();
     bool have = false, drained = false;
-    uint32_t gb = 0, pos = 0, end = 0;
+    uint32_t out_slot = 0, pos = 0, end = 0;
     XYZZ<C> acc;
     xyzz_set_inf(acc);
     for (;;) {
-        // ---- lanes without a bucket take the next position of the wave's batch
+        // ---- lanes without work take the next position of the wave's batch: a (bucket, piece) pair
         bool want_refill = false;
         if (!have && !drained) {
             const uint32_t i = atomicAdd(&s_next, 1u);
             if (i < s_end) {
-                const uint32_t r = i / per_rank, rem = i % per_rank;
+                const uint32_t ib = i >> sh.split_log, piece = i & (S - 1);
+                const uint32_t r = ib / per_rank, rem = ib % per_rank;
                 const uint32_t g = rem / 64, slot = r * 64 + (rem % 64);
                 if (slot < sh.rb) {
-                    gb = order[(uint64_t)g * sh.rb + slot];
-                    const uint32_t start = offs[gb], cnt = counts[gb];
+                    const uint32_t gb = order[(uint64_t)g * sh.rb + slot];
+                    const uint32_t cnt = counts[gb];
+                    out_slot = (gb << sh.split_log) + piece;
+                    // this lane's share of the bucket's sorted slice
+                    const uint32_t plen = (cnt + S - 1) >> sh.split_log;
+                    uint32_t lo = piece * plen, hi = lo + plen;
+                    if (lo > cnt) lo = cnt;
+                    if (hi > cnt) hi = cnt;
+                    const uint32_t start = offs[gb];
                     if (cnt > sh.big_thresh) {
-                        const uint32_t ns = (cnt + MSM_SEG - 1) / MSM_SEG;
-                        const uint32_t bi = atomicAdd(&q->nbig, 1u);
-                        const uint32_t s0 = atomicAdd(&q->nseg, ns);
-                        big_list[2 * bi] = gb;
-                        big_list[2 * bi + 1] = s0;
-                        for (uint32_t k = 0; k < ns; k++) {
-                            MsmSeg sg;
-                            sg.bucket = gb;
-                            sg.start = start + k * MSM_SEG;
-                            sg.len = (k + 1 == ns) ? cnt - k * MSM_SEG : MSM_SEG;
-                            sg.big_index = bi;
-                            seg_list[s0 + k] = sg;
-                        }
-                    } else if (cnt == 0) {
                         xyzz_set_inf(acc);
-                        buckets[gb] = acc;
+                        buckets[out_slot] = acc;   // the cooperative path below owns this bucket
+                        if (piece == 0) {   // (no `continue` here: every lane must reach the wave votes below)
+                            const uint32_t ns = (cnt + MSM_SEG - 1) / MSM_SEG;
+                            const uint32_t bi = atomicAdd(&q->nbig, 1u);
+                            const uint32_t s0 = atomicAdd(&q->nseg, ns);
+                            big_list[2 * bi] = gb;
+                            big_list[2 * bi + 1] = s0;
+                            for (uint32_t k = 0; k < ns; k++) {
+                                MsmSeg sg;
+                                sg.bucket = gb;
+                                sg.start = start + k * MSM_SEG;
+                                sg.len = (k + 1 == ns) ? cnt - k * MSM_SEG : MSM_SEG;
+                                sg.big_index = bi;
+                                seg_list[s0 + k] = sg;
+                            }
+                        }
+                    } else if (lo == hi) {
+                        xyzz_set_inf(acc);
+                        buckets[out_slot] = acc;
                     } else {
                         have = true;
-                        pos = start;
-                        end = start + cnt;
+                        pos = start + lo;
+                        end = start + hi;
                         xyzz_set_inf(acc);
                     }
                 }
@@ -307,7 +321,7 @@ __global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __r
             aff_neg_if(p, (e >> 31) != 0);
             xyzz_add_mixed(acc, p);
             if (++pos == end) {
-                buckets[gb] = acc;
+                buckets[out_slot] = acc;
                 have = false;
             }
         }
@@ -322,6 +336,20 @@ __global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __r
         }
         if (__syncthreads_count(have || !drained) == 0) break;  // every lane has stored its last bucket
     }
+}
+
+// buckets[gb] = sum of the 2^split_log pieces of bucket gb (only launched when split_log > 0)
+template <class C>
+__global__ void __launch_bounds__(64) msm_combine_sub_kernel(const XYZZ<C>* __restrict__ sub, XYZZ<C>* __restrict__ buckets, uint32_t nbuckets,
+                                                             int split_log) {
+    const uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gb >= nbuckets) return;
+    XYZZ<C> acc = sub[(uint64_t)gb << split_log];
+    for (uint32_t s = 1; s < (1u << split_log); s++) {
+        XYZZ<C> p = sub[((uint64_t)gb << split_log) + s];
+        xyzz_add(acc, p);
+    }
+    buckets[gb] = acc;
 }
 
 // One wave per segment of an oversized bucket: lane-strided partial sums + LDS tree.

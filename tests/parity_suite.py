@@ -343,3 +343,20 @@ def check_ntt_fused_coset(zk, name, logn, threads=8):
     # standalone coset_mul on a device buffer
     d = to_device(zk, a)
     assert (to_host(zk, zk.coset_mul(name, d, g)) == orc.distribute_powers(name, a, g)).all()
+
+
+def check_msm_split(zk, cname, n, window_bits, realistic=True):
+    """bucket splitting (every bucket's slice summed by 2^k lanes, then combined) for k = 0..3, including oversized
+    buckets (realistic mix) and buckets shorter than the number of pieces"""
+    pts = bases_for(cname, n)
+    sc = scalars_for(cname, n, 43, realistic=realistic)
+    exp = orc.msm_ark(cname, pts, sc, threads=8)
+    bases = zk.Bases(cname, pts)
+    try:
+        for k in (0, 1, 2, 3):
+            os.environ["ZK_MSM_SPLIT"] = str(k)
+            got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
+            assert (got == exp).all(), (cname, n, k)
+    finally:
+        os.environ.pop("ZK_MSM_SPLIT", None)
+    bases.free()

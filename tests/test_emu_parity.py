@@ -89,3 +89,10 @@ def test_ntt_fused_coset(zk, monkeypatch):
         ps.check_ntt_fused_coset(zk, name, logn)
     monkeypatch.setenv("ZK_NTT_MAX_LOGR", "3")   # three passes: pre on the first, post on the last
     ps.check_ntt_fused_coset(zk, "Bls381Fr", 8)
+
+
+def test_msm_bucket_splitting(zk):
+    ps.check_msm_split(zk, "Vesta", 400, 5)
+    ps.check_msm_split(zk, "Bls381G1", 150, 4, realistic=False)
+    ps.check_msm_split(zk, "Pallas", 3000, 6)        # oversized buckets + splitting
+    ps.check_msm_split(zk, "Bn254G2", 60, 3)

@@ -119,6 +119,12 @@ def test_msm_window_groups(zk, cname):
     ps.check_msm_groups(zk, cname, 70000, 16)      # the default plan switches the pipeline on from 2^16 points
 
 
+@pytest.mark.parametrize("cname", ["Vesta", "Bn254G1", "Bls381G1", "Bn254G2"])
+def test_msm_bucket_splitting(zk, cname):
+    ps.check_msm_split(zk, cname, 1 << 13, 0)
+    ps.check_msm_split(zk, cname, 50000, 12, realistic=False)
+
+
 def _device_bases(zk, cname, n, seed=77):
     """bases generated on the GPU: P_i = [k_i]G via zk_fixed_base_mul_device; spot-checked on the oracle."""
     import torch
