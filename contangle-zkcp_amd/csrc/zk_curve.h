@@ -158,13 +158,15 @@ ZK_HD void xyzz_add_mixed(XYZZ<C>& acc, const Affine<C>& q) {
     fe_mul(acc.zzz, acc.zzz, ppp);
 }
 
-// add-2008-s: acc += q (both XYZZ), all special cases handled
+// add-2008-s without the doubling branch: acc += q unless acc == q, in which case acc is left alone and true is returned
+// (the caller doubles).  Split this way so that a kernel can keep ONE inlined copy of the addition and ONE of the doubling:
+// an inlined XYZZ addition is 25-40 KB of code and the instruction cache (shared by two CUs) holds 64 KB.
 template <class C>
-ZK_HD void xyzz_add(XYZZ<C>& acc, const XYZZ<C>& q) {
-    if (xyzz_is_inf(q)) return;
+ZK_HD bool xyzz_add_nodbl(XYZZ<C>& acc, const XYZZ<C>& q) {
+    if (xyzz_is_inf(q)) return false;
     if (xyzz_is_inf(acc)) {
         acc = q;
-        return;
+        return false;
     }
     Coord<C> u1, u2, s1, s2, p, r, pp, ppp, qq, t;
     fe_mul(u1, acc.x, q.zz);
@@ -174,12 +176,9 @@ ZK_HD void xyzz_add(XYZZ<C>& acc, const XYZZ<C>& q) {
     fe_sub(p, u2, u1);
     fe_sub(r, s2, s1);
     if (fe_is_zero(p)) {
-        if (fe_is_zero(r)) {
-            xyzz_dbl(acc);
-        } else {
-            xyzz_set_inf(acc);
-        }
-        return;
+        if (fe_is_zero(r)) return true;   // same point
+        xyzz_set_inf(acc);                // opposite points
+        return false;
     }
     fe_sqr(pp, p);
     fe_mul(ppp, p, pp);
@@ -196,6 +195,13 @@ ZK_HD void xyzz_add(XYZZ<C>& acc, const XYZZ<C>& q) {
     fe_mul(acc.zz, acc.zz, pp);
     fe_mul(acc.zzz, acc.zzz, q.zzz);
     fe_mul(acc.zzz, acc.zzz, ppp);
+    return false;
+}
+
+// add-2008-s: acc += q (both XYZZ), all special cases handled
+template <class C>
+ZK_HD void xyzz_add(XYZZ<C>& acc, const XYZZ<C>& q) {
+    if (xyzz_add_nodbl(acc, q)) xyzz_dbl(acc);
 }
 
 // XYZZ -> Jacobian: (X*ZZ, Y*ZZZ, ZZ) satisfies x = X'/Z'^2, y = Y'/Z'^3.  Identity -> (0, R, 0)

@@ -149,15 +149,15 @@ ZK_HD void xyzz_add_mixed(XYZZ<C29<C>>& acc, const Affine<C29<C>>& q) {
     fe29_mul(acc.zzz, acc.zzz, ppp);
 }
 
-// acc += q (both XYZZ): add-2008-s
+// acc += q (both XYZZ) unless acc == q (then acc is untouched and true is returned: the caller doubles): add-2008-s
 template <class C>
-ZK_HD void xyzz_add(XYZZ<C29<C>>& acc, const XYZZ<C29<C>>& q) {
+ZK_HD bool xyzz_add_nodbl(XYZZ<C29<C>>& acc, const XYZZ<C29<C>>& q) {
     using F = typename C::Fq;
     using K = F29<F>;
-    if (xyzz_is_inf(q)) return;
+    if (xyzz_is_inf(q)) return false;
     if (xyzz_is_inf(acc)) {
         acc = q;
-        return;
+        return false;
     }
     Fe29<F> u1, u2, s1, s2, p, r, pp, ppp, qq, rr, t, m1, m2;
     fe29_mul(u1, acc.x, q.zz);
@@ -169,12 +169,9 @@ ZK_HD void xyzz_add(XYZZ<C29<C>>& acc, const XYZZ<C29<C>>& q) {
     uint32_t k;
     if (fe29_zero_filter(p, 3, 5, k) && fe29_is_kp(p, k)) {
         uint32_t kr;
-        if (fe29_zero_filter(r, 3, 5, kr) && fe29_is_kp(r, kr)) {
-            xyzz_dbl(acc);
-        } else {
-            xyzz_set_inf(acc);
-        }
-        return;
+        if (fe29_zero_filter(r, 3, 5, kr) && fe29_is_kp(r, kr)) return true;
+        xyzz_set_inf(acc);
+        return false;
     }
     fe29_norm(p, p);
     fe29_norm(r, r);
@@ -193,6 +190,11 @@ ZK_HD void xyzz_add(XYZZ<C29<C>>& acc, const XYZZ<C29<C>>& q) {
     fe29_mul(acc.zz, acc.zz, pp);
     fe29_mul(acc.zzz, acc.zzz, q.zzz);
     fe29_mul(acc.zzz, acc.zzz, ppp);
+    return false;
+}
+template <class C>
+ZK_HD void xyzz_add(XYZZ<C29<C>>& acc, const XYZZ<C29<C>>& q) {
+    if (xyzz_add_nodbl(acc, q)) xyzz_dbl(acc);
 }
 
 // ---- conversions (bases on upload; partial sums on the host) ----

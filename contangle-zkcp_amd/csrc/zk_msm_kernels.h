@@ -416,38 +416,79 @@ __global__ void __launch_bounds__(256) msm_combine_big_kernel(const MsmQueue* __
 
 // slice t of window w covers bucket indices [t*L, (t+1)*L) (weights index+1):
 //   X_t = sum_l (l+1) B_{tL+l} + [t*L] * sum_l B_{tL+l}
+// The kernel runs at one wave per SIMD, so its instruction stream is all that matters -- and written naively (two additions in
+// the running-sum loop, a doubling and an addition in the multiplier loop, one more addition at the end) it is 175 KB of code
+// against a 64 KB instruction cache: every pass streams from L2 and the kernel slows by 25% whenever the kernel before it
+// has just swept L2 (measured: tools/shard_model.py with ZK_MSM_SPLIT).  It is therefore a little state machine with ONE
+// addition site and ONE doubling site (xyzz_add_nodbl + xyzz_dbl, ~40 KB) and wave-uniform operand selection:
+//   steps 0 .. 2L-1        run += B_l ; wsum += run          (l = L-1 .. 0, the next bucket prefetched under the additions)
+//   then 2 per bit of tL   acc = 2 acc ; acc += run if the bit is set   (MSB first, bit count uniform over the grid)
+//   last                   wsum += acc
 template <class C>
 __global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restrict__ buckets, XYZZ<C>* __restrict__ out, uint32_t nbk, uint32_t L,
                                   uint32_t slices_per_window, uint32_t nslices) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     if (gt >= nslices) return;
     const uint32_t w = gt / slices_per_window, t = gt % slices_per_window;
-    XYZZ<C> run, wsum;
+    XYZZ<C> run, wsum, acc, b;
     xyzz_set_inf(run);
     xyzz_set_inf(wsum);
-    for (int l = (int)L - 1; l >= 0; l--) {
-        const uint32_t i = t * L + (uint32_t)l;
-        if (i < nbk) {
-            XYZZ<C> b = buckets[(uint64_t)w * nbk + i];
-            xyzz_add(run, b);
-        }
-        xyzz_add(wsum, run);
-    }
-    // wsum += [t*L] run   (MSB-first double-and-add on a <= 31-bit multiplier)
+    xyzz_set_inf(acc);
+    xyzz_set_inf(b);
+    const XYZZ<C>* src = buckets + (uint64_t)w * nbk + (uint64_t)t * L;
+    const uint32_t avail = nbk - t * L < L ? nbk - t * L : L;   // the last slice of a window may be short
+    if (avail > 0) b = src[avail - 1];
     const uint32_t m = t * L;
-    if (m != 0 && !xyzz_is_inf(run)) {
-        XYZZ<C> acc;
-        xyzz_set_inf(acc);
-        for (int bit = 31 - __clz(m); bit >= 0; bit--) {
-            xyzz_dbl(acc);
-            if ((m >> bit) & 1) xyzz_add(acc, run);
+    const uint32_t mmax = (slices_per_window - 1) * L;
+    const uint32_t nbits = mmax ? 32u - (uint32_t)__clz(mmax) : 0u;
+    const uint32_t nsteps = 2 * L + 2 * nbits + 1;
+#pragma unroll 1
+    for (uint32_t s = 0; s < nsteps; s++) {
+        XYZZ<C> X, Y;
+        bool dbl = false, on = true;
+        int kind;
+        if (s < 2 * L) {
+            const uint32_t l = L - 1 - (s >> 1);
+            if ((s & 1) == 0) {
+                kind = 0;
+                X = run;
+                Y = b;
+                on = l < avail;
+                if (on && l > 0) b = src[l - 1];
+            } else {
+                kind = 1;
+                X = wsum;
+                Y = run;
+            }
+        } else if (s < 2 * L + 2 * nbits) {
+            const uint32_t j = s - 2 * L, bit = nbits - 1 - (j >> 1);
+            X = acc;
+            Y = run;
+            kind = 2;
+            if ((j & 1) == 0)
+                dbl = true;
+            else
+                on = (m >> bit) & 1;
+        } else {
+            kind = 1;
+            X = wsum;
+            Y = acc;
         }
-        xyzz_add(wsum, acc);
+        bool need = dbl;
+        if (on && !dbl) need = xyzz_add_nodbl(X, Y);
+        if (on && need) xyzz_dbl(X);
+        if (kind == 0)
+            run = X;
+        else if (kind == 1)
+            wsum = X;
+        else
+            acc = X;
     }
     out[gt] = wsum;
 }
 
-// out[s*per_out + o] = sum of in[s*per_in + o*chunk .. +chunk), chunk = 256*E; one workgroup (256 lanes) per output
+// out[s*per_out + o] = sum of in[s*per_in + o*chunk .. +chunk), chunk = TL*E; one workgroup (TL lanes) per output.
+// One addition site for the strided loads and the LDS tree alike (instruction cache, see msm_reduce_kernel); E >= 1.
 template <class C>
 __global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<C>* __restrict__ in, XYZZ<C>* __restrict__ out, uint32_t per_in, uint32_t per_out,
                                uint32_t E) {
@@ -459,22 +500,31 @@ __global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<C>* __restrict_
     const uint32_t lo = o * chunk;
     XYZZ<C> acc;
     xyzz_set_inf(acc);
-    for (uint32_t k = 0; k < E; k++) {
-        const uint32_t i = lo + k * TL + tid;
-        if (i < per_in && i < lo + chunk) {
-            XYZZ<C> b = in[(uint64_t)s * per_in + i];
-            xyzz_add(acc, b);
+    const XYZZ<C>* src = in + (uint64_t)s * per_in;
+    const uint32_t lim = per_in < lo + chunk ? per_in : lo + chunk;
+    XYZZ<C> nxt;
+    xyzz_set_inf(nxt);
+    if (lo + tid < lim) nxt = src[lo + tid];
+    uint32_t nlev = 0;
+    for (uint32_t d = TL / 2; d > 0; d >>= 1) nlev++;
+#pragma unroll 1
+    for (uint32_t k = 0; k < E + nlev; k++) {
+        XYZZ<C> b = nxt;
+        bool on;
+        if (k < E) {
+            const uint32_t i = lo + k * TL + tid;
+            on = i < lim;
+            if (on && k + 1 < E && i + TL < lim) nxt = src[i + TL];   // prefetch: the load overlaps the addition below
+        } else {
+            const uint32_t d = TL >> (k - E + 1);
+            on = tid < d;
+            if (on) b = sh[tid + d];
         }
-    }
-    sh[tid] = acc;
-    __syncthreads();
-    for (uint32_t d = TL / 2; d > 0; d >>= 1) {
-        if (tid < d) {
-            XYZZ<C> b = sh[tid + d];
-            xyzz_add(acc, b);
-            sh[tid] = acc;
+        if (on) xyzz_add(acc, b);
+        if (k + 1 >= E) {
+            if (on || k + 1 == E) sh[tid] = acc;
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (tid == 0) out[(uint64_t)s * per_out + o] = acc;
 }

@@ -20,8 +20,11 @@ torch.cuda.synchronize()
 bases = zk.Bases(curve, device_tensor=d_pts, n=n)
 d_sc = torch.from_numpy(ps.scalars_for(curve, n, 0xC0DE).view(np.int64)).cuda()
 ref = None
-grid = {"ZK_MSM_GROUPS": ["1", "2"], "ZK_MSM_C": ["16", "15"], "ZK_MSM_SLICE": ["4", "16"], "ZK_MSM_WAVES": ["2", "3"]}
-base = {"ZK_MSM_C": "16", "ZK_MSM_SLICE": "8", "ZK_MSM_WAVES": "3", "ZK_MSM_GROUPS": "1"}
+grid = {"ZK_MSM_SPLIT": ["0", "1"], "ZK_MSM_C": ["16", "15"], "ZK_MSM_SLICE": ["1", "2", "4", "16"], "ZK_MSM_WAVES": ["2", "3"]}
+if os.environ.get("TUNE_GRID"):   # e.g. TUNE_GRID='{"ZK_MSM_SLICE": ["2", "4"]}'
+    import json
+    grid = json.loads(os.environ["TUNE_GRID"])
+base = {"ZK_MSM_C": "16", "ZK_MSM_SLICE": "8", "ZK_MSM_WAVES": "3", "ZK_MSM_GROUPS": "1", "ZK_MSM_SPLIT": "1"}
 configs = [dict(base)]
 for k, vals in grid.items():
     for v in vals:
