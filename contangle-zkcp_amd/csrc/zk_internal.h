@@ -18,7 +18,6 @@
 #include "zk_curve.h"
 
 namespace zk {
-constexpr int MSM_MAX_GROUPS = 8;
 
 
 #define HIP_TRY(expr)                                       \
@@ -75,9 +74,8 @@ struct Ctx {
     uint64_t tw_stamp = 0;
     size_t tw_bytes = 0;
     // workspaces (grow-only, reused across calls)
-    DevBuf ntt_tmp, pow_tbl, msm_counts, msm_digits, msm_queue, msm_seg_out, msm_subacc, msm_sorted, msm_buckets, msm_part_a, msm_part_b, scratch_in, scratch_out;
-    hipEvent_t ev[4 + 5 * 8];   // MSM phase events: 4 global + 5 per window group
-    hipStream_t aux_stream = nullptr;
+    DevBuf ntt_tmp, pow_tbl, msm_counts, msm_digits, msm_blockcnt, msm_stage_idx, msm_stage_low, msm_queue, msm_seg_out, msm_subacc, msm_sorted, msm_buckets, msm_part_a, msm_part_b, scratch_in, scratch_out;
+    hipEvent_t ev[6];   // MSM phase events
     bool have_events = false;
     zk_msm_profile prof;
 };

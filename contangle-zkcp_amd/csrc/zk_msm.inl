@@ -44,12 +44,11 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         if (n >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
         MsmShape sh;
         sh.n = (uint32_t)n;
-        sh.n_pad = (uint32_t)((n + 7) & ~7ull);
         sh.c = c;
         sh.w0 = w0;
         sh.nw = w1 - w0;
         sh.nbk = 1u << (c - 1);
-        sh.rb = sh.nbk < 2048u ? sh.nbk : 2048u;
+        sh.rb = sh.nbk < MSM_RANGE ? sh.nbk : MSM_RANGE;
         sh.nranges = sh.nbk / sh.rb;
         sh.mont = mont;
         {   // oversize threshold: 2x the mean bucket length + 64 (uniform 2^20 / c=16: mean 32, max ~70 -> none)
@@ -80,32 +79,37 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
             }
             sh.split_log = sl;
         }
-        // Window groups (experimental, default 1): the windows of the call can be cut into G groups issued alternately on two
-        // HIP streams.  Measured on MI355X at 2^20 (tools/tune_msm.py): G = 2 / 4 is 1.5x / 2.7x SLOWER -- two persistent
-        // accumulate kernels simply share the SIMDs, every group pays its own queue-drain tail, and the later groups' sort
-        // kernels crawl beside the resident accumulate waves.  Kept because the grouped path is what a multi-MSM batch
-        // (several commitments in flight) would use; ZK_MSM_GROUPS selects it.
-        int G = 1;
-        if (const char* e = getenv("ZK_MSM_GROUPS")) {
-            int v = atoi(e);
-            if (v >= 1 && v <= MSM_MAX_GROUPS) G = v;
-        }
-        if (G > nw_all) G = nw_all;
         const uint32_t nbuckets = (uint32_t)nw_all * sh.nbk;
-        const uint32_t nwg_all = (uint32_t)nw_all * sh.nranges;
-        // counts | offs | order | wg_total
-        ZK_TRY(ws_get(g.msm_counts, ((size_t)nbuckets * 3 + nwg_all) * 4));
+        const uint32_t nreg = (uint32_t)nw_all * sh.nranges;                  // (window, bucket range) regions
+        const uint32_t nblocks = (uint32_t)((n + MSM_SBLK - 1) / MSM_SBLK);    // scalar blocks of the count / stage kernels
+        if (nreg > 4096 || sh.nranges > 64) return ZK_ERR_UNSUPPORTED;         // LDS tables of those kernels (c <= 16: <= 1024, 64)
+        // counts | offs | order | wg_total | region_base
+        ZK_TRY(ws_get(g.msm_counts, ((size_t)nbuckets * 3 + 2 * (size_t)nreg) * 4));
         uint32_t* counts = (uint32_t*)g.msm_counts.p;
         uint32_t* offs = counts + nbuckets;
         uint32_t* order = offs + nbuckets;
         uint32_t* wg_total = order + nbuckets;
-        ZK_TRY(ws_get(g.msm_digits, (size_t)sh.n_pad * nw_all * 2));
+        uint32_t* region_base = wg_total + nreg;
+        ZK_TRY(ws_get(g.msm_blockcnt, (size_t)nreg * nblocks * 4));
+        uint32_t* blockcnt = (uint32_t*)g.msm_blockcnt.p;
+        ZK_TRY(ws_get(g.msm_stage_idx, (size_t)n * nw_all * 4));
+        ZK_TRY(ws_get(g.msm_stage_low, (size_t)n * nw_all * 2));
+        ZK_TRY(ws_get(g.msm_digits, (size_t)n * nw_all * 2));
         uint16_t* digits = (uint16_t*)g.msm_digits.p;
+        uint32_t* stage_idx = (uint32_t*)g.msm_stage_idx.p;
+        uint16_t* stage_low = (uint16_t*)g.msm_stage_low.p;
         ZK_TRY(ws_get(g.msm_sorted, (size_t)n * nw_all * 4));
+        uint32_t* sorted = (uint32_t*)g.msm_sorted.p;
         ZK_TRY(ws_get(g.msm_buckets, (size_t)nbuckets * sizeof(XYZZ<CK>)));
-        if (sh.split_log > 0) ZK_TRY(ws_get(g.msm_subacc, ((size_t)nbuckets << sh.split_log) * sizeof(XYZZ<CK>)));
-        // slice length of the bucket reduction: keep ~64K lanes busy whatever the window share of this call (a rank of a
-        // window-sharded MSM owns few windows; shorter slices shorten the dependent chain, which is all this phase costs)
+        XYZZ<CK>* buckets = (XYZZ<CK>*)g.msm_buckets.p;
+        XYZZ<CK>* acc_out = buckets;
+        if (sh.split_log > 0) {
+            ZK_TRY(ws_get(g.msm_subacc, ((size_t)nbuckets << sh.split_log) * sizeof(XYZZ<CK>)));
+            acc_out = (XYZZ<CK>*)g.msm_subacc.p;
+        }
+        // slice length of the bucket reduction: 64K lanes = one wave on every SIMD, which is what saturates the VALUs
+        // (the kernel is instruction-throughput-bound, not latency-bound); a rank of a window-sharded MSM owns few
+        // windows and gets shorter slices
         uint32_t L = (uint32_t)(((uint64_t)nw_all * sh.nbk) >> 16);
         if (L < 1) L = 1;
         if (L > 8) L = 8;
@@ -119,114 +123,86 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         ZK_TRY(ws_get(g.msm_part_a, (size_t)spw * nw_all * sizeof(XYZZ<CK>)));
         ZK_TRY(ws_get(g.msm_part_b, (size_t)pbw * nw_all * sizeof(XYZZ<CK>)));
         // oversized-bucket lists: a bucket above big_thresh yields ceil(cnt / MSM_SEG) segments
-        const size_t max_seg_w = (size_t)n / MSM_SEG + (size_t)n / sh.big_thresh + 2;   // per window
-        const size_t qstride_w = ((sizeof(MsmQueue) + max_seg_w * (sizeof(MsmSeg) + 8) + 15) / 16 + 1) * 16;
-        ZK_TRY(ws_get(g.msm_queue, qstride_w * nw_all + sizeof(MsmQueue) * MSM_MAX_GROUPS));
-        ZK_TRY(ws_get(g.msm_seg_out, max_seg_w * nw_all * sizeof(XYZZ<CK>)));
+        const size_t max_seg = ((size_t)n / MSM_SEG + (size_t)n / sh.big_thresh + 2) * nw_all;
+        ZK_TRY(ws_get(g.msm_queue, sizeof(MsmQueue) + max_seg * (sizeof(MsmSeg) + 8) + 64));
+        ZK_TRY(ws_get(g.msm_seg_out, max_seg * sizeof(XYZZ<CK>)));
+        MsmQueue* q = (MsmQueue*)g.msm_queue.p;
+        MsmSeg* seg_list = (MsmSeg*)(q + 1);
+        uint32_t* big_list = (uint32_t*)(seg_list + max_seg);
+        XYZZ<CK>* seg_out = (XYZZ<CK>*)g.msm_seg_out.p;
+        XYZZ<CK>* cur = (XYZZ<CK>*)g.msm_part_a.p;
+        XYZZ<CK>* nxt = (XYZZ<CK>*)g.msm_part_b.p;
         if (!g.have_events) {
             for (auto& e : g.ev) HIP_TRY(hipEventCreate(&e));
-            HIP_TRY(hipStreamCreateWithFlags(&g.aux_stream, hipStreamNonBlocking));
             g.have_events = true;
         }
-        hipStream_t streams[2] = {st, G > 1 ? g.aux_stream : st};
         // resident waves per SIMD: the F29 kernel holds 138 VGPRs (3 fit), the 32-bit one 119 (4 fit); tools/tune_msm.py
         unsigned waves_per_simd = CK::EXT == 29 ? 3 : 4;
         if (const char* e = getenv("ZK_MSM_WAVES")) {
             int v = atoi(e);
             if (v >= 1 && v <= 8) waves_per_simd = (unsigned)v;
         }
-        const unsigned blk = 256;
-        hipEvent_t* EV = g.ev;   // [0] begin, [1] digits done, [2] aux done, [3] end; then 5 per group
-        HIP_TRY(hipEventRecord(EV[0], st));
-        ZK_LAUNCH((msm_digits_kernel<C>), (unsigned)((sh.n_pad + blk - 1) / blk), blk, 0, st, d_scalars, sh, digits);
-        HIP_TRY(hipEventRecord(EV[1], st));
-        if (G > 1) HIP_TRY(hipStreamWaitEvent(g.aux_stream, EV[1], 0));
-
-        // tree levels of the per-window sums are the same for every group
-        uint32_t per_final = spw;
-        while (per_final > 8) {
-            const uint32_t E = per_final >= 1024 ? 4 : 1;
-            per_final = (per_final + tree_lanes<CK>() * E - 1) / (tree_lanes<CK>() * E);
+        hipEvent_t* ev = g.ev;   // [0] begin, [1] counted, [2] staged, [3] sorted, [4] accumulated, [5] reduced
+        HIP_TRY(hipEventRecord(ev[0], st));
+        // ---- sort: partition the digits by (window, bucket range), then counting-sort every region in LDS
+        const unsigned dblk = n >= 8192 ? 1024u : 256u;   // small problems: fewer lanes, cheaper barriers
+        ZK_LAUNCH((msm_digits_kernel<C>), nblocks, dblk, (size_t)nreg * 4, st, d_scalars, sh, digits, blockcnt);
+        auto lanes_for = [](uint32_t items) {   // workgroup size for a scan over `items` values: a power of two in [64, 1024]
+            unsigned b = 64;
+            while (b < items && b < 1024) b <<= 1;
+            return b;
+        };
+        ZK_LAUNCH((msm_region_scan_kernel<void>), nreg, lanes_for(nblocks), 0, st, blockcnt, nblocks, wg_total);
+        ZK_LAUNCH((msm_region_base_kernel<void>), 1, lanes_for(nreg), 0, st, (const uint32_t*)wg_total, nreg, region_base);
+        HIP_TRY(hipEventRecord(ev[1], st));
+        ZK_LAUNCH((msm_stage_kernel<void>), nblocks * (unsigned)nw_all, dblk, (size_t)MSM_SBLK * 8 + (size_t)(3 * sh.nranges + 1) * 4, st,
+                  (const uint16_t*)digits, sh, (const uint32_t*)blockcnt, (const uint32_t*)wg_total, (const uint32_t*)region_base, nblocks,
+                  stage_idx, stage_low);
+        HIP_TRY(hipEventRecord(ev[2], st));
+        // LDS permutation capacity of a sort workgroup: 1.5x the mean region, at most 24576 entries (57 KB of LDS in all,
+        // two workgroups per CU); larger regions scatter straight to HBM
+        uint32_t cap = (uint32_t)((n / sh.nranges) * 3 / 2 + 64);
+        if (cap > 24576) cap = 24576;
+        cap = (cap + 1) & ~1u;
+        ZK_LAUNCH((msm_sort_kernel<void>), nreg, n >= 8192 ? 1024u : 256u, (size_t)(2 * sh.rb + 1024 + 258) * 4 + (size_t)cap * 2, st,
+                  (const uint32_t*)stage_idx, (const uint16_t*)stage_low, sh, (const uint32_t*)region_base, (const uint32_t*)wg_total, counts,
+                  offs, order, sorted, cap);
+        HIP_TRY(hipEventRecord(ev[3], st));
+        // ---- persistent accumulate: lanes stream buckets, largest first; oversized buckets go to the cooperative segment
+        // kernels (fixed grids over device-side lists, no host round trip)
+        HIP_TRY(hipMemsetAsync(q, 0, sizeof(MsmQueue), st));
+        const uint32_t ntasks = (((nreg * ((sh.rb + MSM_RANKW - 1) / MSM_RANKW) * MSM_RANKW) << sh.split_log) + MSM_BATCH - 1) / MSM_BATCH;  // batches in the queue
+        unsigned acc_grid = (g.num_cus > 0 ? (unsigned)g.num_cus : 256u) * 4u * waves_per_simd;
+        if (acc_grid > ntasks) acc_grid = ntasks;
+        ZK_LAUNCH((msm_accumulate_kernel<CK>), acc_grid, 64, 0, st, bases, (const uint32_t*)sorted, (const uint32_t*)offs,
+                  (const uint32_t*)counts, (const uint32_t*)order, acc_out, sh, q, seg_list, big_list);
+        if (sh.split_log > 0)
+            ZK_LAUNCH((msm_combine_sub_kernel<CK>), (nbuckets + 63) / 64, 64, 0, st, (const XYZZ<CK>*)acc_out, buckets, nbuckets, sh.split_log);
+        const unsigned big_grid = max_seg < 4096 ? (unsigned)max_seg : 4096u;
+        ZK_LAUNCH((msm_accumulate_big_kernel<CK>), big_grid, 64, 0, st, bases, (const uint32_t*)sorted, (const MsmQueue*)q,
+                  (const MsmSeg*)seg_list, seg_out);
+        ZK_LAUNCH((msm_combine_big_kernel<CK>), big_grid < 64 ? big_grid : 64u, tree_lanes<CK>(), 0, st, (const MsmQueue*)q,
+                  (const uint32_t*)big_list, (const uint32_t*)counts, (const XYZZ<CK>*)seg_out, buckets);
+        HIP_TRY(hipEventRecord(ev[4], st));
+        // ---- bucket reduction, then tree-sum the slices of each window until <= 8 remain
+        const uint32_t nslices = spw * (uint32_t)nw_all;
+        ZK_LAUNCH((msm_reduce_kernel<CK>), (nslices + 63) / 64, 64, 0, st, (const XYZZ<CK>*)buckets, cur, sh.nbk, L, spw, nslices);
+        uint32_t per = spw;
+        while (per > 8) {
+            const uint32_t E = per >= 1024 ? 4 : 1;
+            const uint32_t chunk = tree_lanes<CK>() * E;
+            const uint32_t per_out = (per + chunk - 1) / chunk;
+            ZK_LAUNCH((msm_sum_kernel<CK>), (unsigned)nw_all * per_out, tree_lanes<CK>(), 0, st, (const XYZZ<CK>*)cur, nxt, per, per_out, E);
+            per = per_out;
+            XYZZ<CK>* t = cur;
+            cur = nxt;
+            nxt = t;
         }
-        std::vector<XYZZ<CK>> host((size_t)nw_all * per_final);
-
-        for (int gi = 0; gi < G; gi++) {
-            hipStream_t S = streams[gi & 1];
-            hipEvent_t* ev = EV + 4 + 5 * gi;
-            const int lw0 = nw_all * gi / G, lw1 = nw_all * (gi + 1) / G;
-            MsmShape sg = sh;
-            sg.w0 = w0 + lw0;
-            sg.nw = lw1 - lw0;
-            const uint32_t nb_g = (uint32_t)sg.nw * sh.nbk;
-            const uint32_t nwg = (uint32_t)sg.nw * sh.nranges;
-            uint32_t* counts_g = counts + (size_t)lw0 * sh.nbk;
-            uint32_t* offs_g = offs + (size_t)lw0 * sh.nbk;
-            uint32_t* order_g = order + (size_t)lw0 * sh.nbk;
-            uint32_t* wg_total_g = wg_total + (size_t)lw0 * sh.nranges;
-            const uint16_t* digits_g = digits + (size_t)lw0 * sh.n_pad;
-            uint32_t* sorted_g = (uint32_t*)g.msm_sorted.p + (size_t)lw0 * n;
-            XYZZ<CK>* buckets_g = (XYZZ<CK>*)g.msm_buckets.p + (size_t)lw0 * sh.nbk;
-            XYZZ<CK>* acc_out_g = sh.split_log > 0 ? (XYZZ<CK>*)g.msm_subacc.p + (((size_t)lw0 * sh.nbk) << sh.split_log) : buckets_g;
-            char* qbase = (char*)g.msm_queue.p + qstride_w * lw0;
-            MsmQueue* q = (MsmQueue*)qbase;
-            const size_t max_seg = max_seg_w * sg.nw;
-            MsmSeg* seg_list = (MsmSeg*)(q + 1);
-            uint32_t* big_list = (uint32_t*)(seg_list + max_seg);
-            XYZZ<CK>* seg_out = (XYZZ<CK>*)g.msm_seg_out.p + max_seg_w * lw0;
-            XYZZ<CK>* cur = (XYZZ<CK>*)g.msm_part_a.p + (size_t)spw * lw0;
-            XYZZ<CK>* nxt = (XYZZ<CK>*)g.msm_part_b.p + (size_t)pbw * lw0;
-            // the first group's sort runs alone on the chip: 16 waves per workgroup; later groups must fit beside the
-            // resident accumulate waves: 4 waves per workgroup
-            const unsigned sblk = (gi == 0 && sh.n_pad >= 8192) ? 1024 : 256;
-            HIP_TRY(hipEventRecord(ev[0], S));
-            ZK_LAUNCH((msm_hist_kernel<void>), nwg, sblk, (size_t)(sh.rb + 1) * 4, S, digits_g, sg, counts_g, wg_total_g);
-            HIP_TRY(hipEventRecord(ev[1], S));
-            ZK_LAUNCH((msm_scatter_kernel<void>), nwg, sblk, (size_t)(sh.rb + 1024 + 258) * 4, S, digits_g, sg,
-                      (const uint32_t*)counts_g, (const uint32_t*)wg_total_g, offs_g, order_g, sorted_g);
-            HIP_TRY(hipEventRecord(ev[2], S));
-            // persistent accumulate: lanes stream buckets, largest first; oversized buckets go to the cooperative segment
-            // kernels (fixed grids over device-side lists, no host round trip)
-            HIP_TRY(hipMemsetAsync(q, 0, sizeof(MsmQueue), S));
-            const uint32_t ntasks = (((nwg * ((sh.rb + 63) / 64) * 64) << sh.split_log) + MSM_BATCH - 1) / MSM_BATCH;  // batches in the queue
-            unsigned acc_grid = (g.num_cus > 0 ? (unsigned)g.num_cus : 256u) * 4u * waves_per_simd;
-            if (acc_grid > ntasks) acc_grid = ntasks;
-            ZK_LAUNCH((msm_accumulate_kernel<CK>), acc_grid, 64, 0, S, bases, (const uint32_t*)sorted_g, (const uint32_t*)offs_g,
-                      (const uint32_t*)counts_g, (const uint32_t*)order_g, acc_out_g, sg, q, seg_list, big_list);
-            if (sh.split_log > 0)
-                ZK_LAUNCH((msm_combine_sub_kernel<CK>), (nb_g + 63) / 64, 64, 0, S, (const XYZZ<CK>*)acc_out_g, buckets_g, nb_g, sh.split_log);
-            const unsigned big_grid = max_seg < 4096 ? (unsigned)max_seg : 4096u;
-            ZK_LAUNCH((msm_accumulate_big_kernel<CK>), big_grid, 64, 0, S, bases, (const uint32_t*)sorted_g, (const MsmQueue*)q,
-                      (const MsmSeg*)seg_list, seg_out);
-            ZK_LAUNCH((msm_combine_big_kernel<CK>), big_grid < 64 ? big_grid : 64u, tree_lanes<CK>(), 0, S, (const MsmQueue*)q,
-                      (const uint32_t*)big_list, (const uint32_t*)counts_g, (const XYZZ<CK>*)seg_out, buckets_g);
-            HIP_TRY(hipEventRecord(ev[3], S));
-            const uint32_t nslices = spw * (uint32_t)sg.nw;
-            ZK_LAUNCH((msm_reduce_kernel<CK>), (nslices + 63) / 64, 64, 0, S, (const XYZZ<CK>*)buckets_g, cur, sh.nbk, L, spw, nslices);
-            // tree-sum the slices of each window until <= 8 remain
-            uint32_t per = spw;
-            while (per > 8) {
-                const uint32_t E = per >= 1024 ? 4 : 1;
-                const uint32_t chunk = tree_lanes<CK>() * E;
-                const uint32_t per_out = (per + chunk - 1) / chunk;
-                ZK_LAUNCH((msm_sum_kernel<CK>), (unsigned)sg.nw * per_out, tree_lanes<CK>(), 0, S, (const XYZZ<CK>*)cur, nxt, per, per_out, E);
-                per = per_out;
-                XYZZ<CK>* t = cur;
-                cur = nxt;
-                nxt = t;
-            }
-            HIP_TRY(hipEventRecord(ev[4], S));
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(host.data() + (size_t)lw0 * per_final, cur, (size_t)sg.nw * per_final * sizeof(XYZZ<CK>),
-                                   hipMemcpyDeviceToHost, S));
-        }
-        if (G > 1) {
-            HIP_TRY(hipEventRecord(EV[2], g.aux_stream));
-            HIP_TRY(hipStreamWaitEvent(st, EV[2], 0));
-        }
-        HIP_TRY(hipEventRecord(EV[3], st));
+        HIP_TRY(hipEventRecord(ev[5], st));
+        HIP_TRY(hipGetLastError());
+        std::vector<XYZZ<CK>> host((size_t)nw_all * per);
+        HIP_TRY(hipMemcpyAsync(host.data(), cur, host.size() * sizeof(XYZZ<CK>), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (G > 1) HIP_TRY(hipStreamSynchronize(g.aux_stream));
-        const uint32_t per = per_final;
         const double t0 = now_ms();
         // Horner over this call's windows, high to low, then the shift by 2^(c*w0) -- on 64-bit host limbs
         HostXYZZ<C> htotal, hp;
@@ -243,23 +219,14 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         for (int k = 0; k < c * w0; k++) xyzz_dbl(htotal);
         from_host<C>(total, htotal);
         g.prof.host_tail_ms = (float)(now_ms() - t0);
-        // phase times are summed over the groups (they overlap in wall time when G > 1); total_ms is wall time
-        hipEventElapsedTime(&g.prof.digits_ms, EV[0], EV[1]);
-        for (int gi = 0; gi < G; gi++) {
-            hipEvent_t* ev = EV + 4 + 5 * gi;
-            float t;
-            hipEventElapsedTime(&t, ev[0], ev[1]);
-            g.prof.hist_ms += t;
-            hipEventElapsedTime(&t, ev[1], ev[2]);
-            g.prof.scatter_ms += t;
-            hipEventElapsedTime(&t, ev[2], ev[3]);
-            g.prof.accumulate_ms += t;
-            hipEventElapsedTime(&t, ev[3], ev[4]);
-            g.prof.reduce_ms += t;
-        }
-        hipEventElapsedTime(&g.prof.total_ms, EV[0], EV[3]);
+        hipEventElapsedTime(&g.prof.digits_ms, ev[0], ev[1]);
+        hipEventElapsedTime(&g.prof.hist_ms, ev[1], ev[2]);
+        hipEventElapsedTime(&g.prof.scatter_ms, ev[2], ev[3]);
+        hipEventElapsedTime(&g.prof.accumulate_ms, ev[3], ev[4]);
+        hipEventElapsedTime(&g.prof.reduce_ms, ev[4], ev[5]);
+        hipEventElapsedTime(&g.prof.total_ms, ev[0], ev[5]);
         g.prof.total_ms += g.prof.host_tail_ms;
-        g.prof.groups = G;
+        g.prof.groups = 1;
     }
     xyzz_to_jacobian(result, total);
     memcpy(out_jac, &result, 3 * sizeof(uint32_t) * coord_words<C>());

@@ -17,26 +17,29 @@ namespace zk {
 
 // ------------------------------------------------------------------------------------------
 // MSM: signed-digit Pippenger.
-//   1. msm_digits_kernel     scalar -> W signed c-bit digits, stored as u16 codes, window-major
-//   2. msm_hist_kernel       one workgroup per (window, bucket range): LDS histogram of its range
-//   3. msm_scatter_kernel    same grid: LDS scan -> bucket offsets, size-ordered bucket list, and the
-//                            counting-sort scatter of (point index | sign) through LDS cursors
-//   4. msm_accumulate_kernel one lane per bucket (largest first), XYZZ mixed adds over its slice
-//   5. msm_reduce_kernel     sum_b b*B_b by slices: X_t = W_t + [t*L] S_t
-//   6. msm_sum_kernel        per-window tree sums of X_t
+//   1. msm_digits_kernel     scalar -> W signed c-bit digits (u16 codes, window-major) + per block of 4096 scalars the
+//                            number of non-zero digits in each (window, bucket range) region
+//   2. msm_region_scan_kernel / msm_region_base_kernel   block offsets inside each region, region bases
+//   3. msm_stage_kernel      per (block, window): partition the digits by range inside LDS, copy the chunks to their
+//                            regions: (point index | sign) and the bucket number inside the range
+//   4. msm_sort_kernel       one workgroup per region: LDS histogram of its buckets, LDS scan -> bucket offsets and the
+//                            size-ordered bucket list, counting sort inside LDS, one coalesced store of the region
+//   5. msm_accumulate_kernel one lane per bucket (largest first), XYZZ mixed adds over its slice
+//   6. msm_reduce_kernel     sum_b b*B_b by slices: X_t = W_t + [t*L] S_t
+//   7. msm_sum_kernel        per-window tree sums of X_t
 //   host: <= a few points per window, Horner over windows (c doublings each).
 // Digits are in [-(2^(c-1)-1), 2^(c-1)]; bucket index b-1 (b = |digit| in 1..2^(c-1)) holds the sum of
-// (+-)P_i.  No global atomics: every counter lives in the LDS of the workgroup that owns its bucket
-// range, and each workgroup scatters into its own contiguous slice of the sorted array (so the
-// 4-byte scattered stores combine in that XCD's L2 before they reach HBM).
+// (+-)P_i.  No global atomics in the sort: every counter lives in LDS, and both sorting steps permute inside LDS and
+// store contiguous chunks.  Every digit is touched four times (digit, stage, histogram, scatter) whatever the number
+// of ranges -- the first version had each (window, range) workgroup filter the whole digit row of its window (16 x
+// redundant at c = 16) and scatter 4-byte stores across its region.
 // ------------------------------------------------------------------------------------------
 struct MsmShape {
     uint32_t n;
-    uint32_t n_pad;   // digit row stride (u16 elements), multiple of 8 so rows are 16-byte aligned
     int c;            // window bits (<= 16)
     int w0, nw;       // this call accumulates windows [w0, w0 + nw) of the scalar (window-range sharding)
     uint32_t nbk;     // buckets per window = 2^(c-1)
-    uint32_t rb;      // buckets per workgroup range
+    uint32_t rb;      // buckets per range (power of two, <= 512: a region of the sorted array should fit the LDS of its sort workgroup)
     uint32_t nranges; // ranges per window = nbk / rb
     int mont;         // scalars arrive in Montgomery form (halo2) rather than canonical (ark BigInt)
     uint32_t big_thresh;  // buckets longer than this take the cooperative path
@@ -58,6 +61,9 @@ __device__ __forceinline__ uint32_t bits_at(const uint32_t (&s)[N], int start, i
     return (uint32_t)(v >> off) & ((1u << c) - 1);
 }
 
+constexpr uint32_t MSM_RANGE = 512;   // buckets per (window, range) region of the sort
+constexpr uint32_t MSM_SBLK = 4096;   // scalars per workgroup of the digit / stage kernels (1024 lanes x 4)
+
 // u16 digit code: two's complement of the signed digit; positive magnitudes reach 2^15 (0x8000),
 // negative ones only 2^15 - 1, so the code is unambiguous:  neg <=> code > 0x8000.
 __device__ __forceinline__ uint32_t digit_mag(uint32_t code, bool& neg) {
@@ -65,103 +71,188 @@ __device__ __forceinline__ uint32_t digit_mag(uint32_t code, bool& neg) {
     return neg ? 0x10000u - code : code;
 }
 
+// grid = ceil(n / MSM_SBLK).  Writes the digit codes window-major (digits[w * n + i]) and counts this block's non-zero
+// digits per region: blockcnt[region * nblocks + block], region = window * nranges + range
 template <class C>
-__global__ void __launch_bounds__(256) msm_digits_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh,
-                                                         uint16_t* __restrict__ digits) {
+__global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh,
+                                                          uint16_t* __restrict__ digits, uint32_t* __restrict__ blockcnt) {
     using Fr = typename C::Fr;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sh.n_pad) return;
-    if (i >= sh.n) {  // row padding: zero digits
-        for (int w = 0; w < sh.nw; w++) digits[(uint64_t)w * sh.n_pad + i] = 0;
-        return;
-    }
-    Fe<Fr> x = scalars[i];
-    if (sh.mont) fe_from_mont(x, x);
-    uint32_t carry = 0;
-    for (int w = 0; w < sh.w0 + sh.nw; w++) {
-        const uint32_t raw = bits_at<Fr::N>(x.v, w * sh.c, sh.c) + carry;
-        const bool neg = raw > sh.nbk;
-        const uint32_t mag = neg ? (1u << sh.c) - raw : raw;
-        carry = neg ? 1u : 0u;
-        if (w >= sh.w0) digits[(uint64_t)(w - sh.w0) * sh.n_pad + i] = (uint16_t)(neg ? 0x10000u - mag : mag);
-    }
-}
-
-// visits every digit of window row `row` whose bucket falls in [lo, lo + rb): f(point index, bucket - lo, neg)
-template <class Fn>
-__device__ __forceinline__ void for_digits_in_range(const uint16_t* __restrict__ row, uint32_t n_pad, uint32_t lo, uint32_t rb,
-                                                    Fn&& f) {
-    const uint4* __restrict__ row4 = reinterpret_cast<const uint4*>(row);
-    const uint32_t nvec = n_pad >> 3;
-    for (uint32_t v = threadIdx.x; v < nvec; v += blockDim.x) {
-        const uint4 q = row4[v];
-        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-        ZK_UNROLL
-        for (int k = 0; k < 8; k++) {
-            const uint32_t code = (wds[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
-            bool neg;
-            const uint32_t mag = digit_mag(code, neg);
-            const uint32_t j = mag - 1 - lo;  // mag == 0 wraps to a huge value
-            if (j < rb) f(v * 8 + k, j, neg);
+    ZK_DYN_SHARED(uint32_t, cnt);   // nw * nranges
+    const uint32_t nreg = (uint32_t)sh.nw * sh.nranges;
+    const uint32_t rb_log = 31u - (uint32_t)__clz(sh.rb);
+    for (uint32_t j = threadIdx.x; j < nreg; j += blockDim.x) cnt[j] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < MSM_SBLK; k += blockDim.x) {
+        const uint32_t i = blockIdx.x * MSM_SBLK + k;
+        if (i >= sh.n) break;
+        Fe<Fr> x = scalars[i];
+        if (sh.mont) fe_from_mont(x, x);
+        uint32_t carry = 0;
+        for (int w = 0; w < sh.w0 + sh.nw; w++) {
+            const uint32_t raw = bits_at<Fr::N>(x.v, w * sh.c, sh.c) + carry;
+            const bool neg = raw > sh.nbk;
+            const uint32_t mag = neg ? (1u << sh.c) - raw : raw;
+            carry = neg ? 1u : 0u;
+            if (w >= sh.w0) {
+                const uint32_t wl = (uint32_t)(w - sh.w0);
+                digits[(uint64_t)wl * sh.n + i] = (uint16_t)(neg ? 0x10000u - mag : mag);
+                if (mag != 0) atomicAdd(&cnt[wl * sh.nranges + ((mag - 1) >> rb_log)], 1u);
+            }
         }
     }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < nreg; j += blockDim.x) blockcnt[(uint64_t)j * gridDim.x + blockIdx.x] = cnt[j];
 }
 
-// grid = nw * nranges, workgroup (w, h) owns buckets [h*rb, (h+1)*rb) of window w
+// grid = regions: exclusive scan of the region's block counts in place; wg_total[region] = their sum
 template <class Tag>
-__global__ void __launch_bounds__(1024) msm_hist_kernel(const uint16_t* __restrict__ digits, MsmShape sh, uint32_t* __restrict__ counts,
-                                                        uint32_t* __restrict__ wg_total) {
-    ZK_DYN_SHARED(uint32_t, hist);  // rb counters (+ 1 total)
-    const uint32_t w = blockIdx.x / sh.nranges, h = blockIdx.x % sh.nranges;
-    const uint32_t lo = h * sh.rb;
-    for (uint32_t j = threadIdx.x; j <= sh.rb; j += blockDim.x) hist[j] = 0;
-    __syncthreads();
-    for_digits_in_range(digits + (uint64_t)w * sh.n_pad, sh.n_pad, lo, sh.rb,
-                        [&](uint32_t, uint32_t j, bool) { atomicAdd(&hist[j], 1u); });
-    __syncthreads();
-    uint32_t local = 0;
-    for (uint32_t j = threadIdx.x; j < sh.rb; j += blockDim.x) {
-        const uint32_t v = hist[j];
-        counts[(uint64_t)w * sh.nbk + lo + j] = v;
-        local += v;
-    }
-    atomicAdd(&hist[sh.rb], local);
-    __syncthreads();
-    if (threadIdx.x == 0) wg_total[blockIdx.x] = hist[sh.rb];
-}
-
-// same grid.  LDS: cur[rb] | part[1024] | bins[258]
-template <class Tag>
-__global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __restrict__ digits, MsmShape sh,
-                                                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ wg_total,
-                                                           uint32_t* __restrict__ offs, uint32_t* __restrict__ order,
-                                                           uint32_t* __restrict__ sorted) {
-    ZK_DYN_SHARED(uint32_t, lds);
-    uint32_t* cur = lds;
-    uint32_t* part = lds + sh.rb;
-    uint32_t* bins = part + 1024;
+__global__ void __launch_bounds__(1024) msm_region_scan_kernel(uint32_t* __restrict__ blockcnt, uint32_t nblocks, uint32_t* __restrict__ wg_total) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry_s;
     const uint32_t tid = threadIdx.x, nth = blockDim.x;
-    const uint32_t w = blockIdx.x / sh.nranges, h = blockIdx.x % sh.nranges;
-    const uint32_t lo = h * sh.rb;
-    const uint64_t gb0 = (uint64_t)w * sh.nbk + lo;
-    // base = number of entries owned by the workgroups before this one
-    uint32_t s = 0;
-    for (uint32_t g = tid; g < blockIdx.x; g += nth) s += wg_total[g];
-    part[tid] = s;
-    for (uint32_t j = tid; j < 258; j += nth) bins[j] = 0;
+    uint32_t* row = blockcnt + (uint64_t)blockIdx.x * nblocks;
+    if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t d = nth >> 1; d > 0; d >>= 1) {
-        if (tid < d) part[tid] += part[tid + d];
+    for (uint32_t base = 0; base < nblocks; base += nth) {
+        const uint32_t v = base + tid < nblocks ? row[base + tid] : 0;
+        part[tid] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < nth; d <<= 1) {
+            const uint32_t u = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += u;
+            __syncthreads();
+        }
+        const uint32_t carry = carry_s;
+        if (base + tid < nblocks) row[base + tid] = carry + part[tid] - v;
+        __syncthreads();
+        if (tid == nth - 1) carry_s = carry + part[tid];
         __syncthreads();
     }
-    const uint32_t base = part[0];
+    if (tid == 0) wg_total[blockIdx.x] = carry_s;
+}
+
+// one workgroup: region_base[r] = sum of wg_total[0 .. r)   (a thousand regions at most)
+template <class Tag>
+__global__ void __launch_bounds__(1024) msm_region_base_kernel(const uint32_t* __restrict__ wg_total, uint32_t nreg, uint32_t* __restrict__ region_base) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint32_t per = (nreg + nth - 1) / nth;
+    const uint32_t lo = tid * per < nreg ? tid * per : nreg, hi = lo + per < nreg ? lo + per : nreg;
+    uint32_t sum = 0;
+    for (uint32_t j = lo; j < hi; j++) sum += wg_total[j];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < nth; d <<= 1) {
+        const uint32_t u = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += u;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (uint32_t j = lo; j < hi; j++) {
+        region_base[j] = run;
+        run += wg_total[j];
+    }
+}
+
+// grid = nblocks * nw: workgroup (block b, window w) partitions the <= MSM_SBLK digits of its block by bucket range INSIDE
+// LDS and then copies every range's chunk to its place in the region (window, range): entry = (point index | sign << 31)
+// in stage_idx and the bucket number inside the range in stage_low.  The copy is what makes this cheap: a lane-per-digit
+// scatter would issue one 4-byte store request per digit to L2 (33 M requests at 2^20 x 16), the chunk copy issues a
+// few requests per 64-entry chunk.
+// LDS: e_idx[MSM_SBLK] u32 | starts[R + 1] | gdst[R] | lcur[R] | e_low[MSM_SBLK] u16 | e_h[MSM_SBLK] u16      (R = nranges <= 64)
+template <class Tag>
+__global__ void __launch_bounds__(1024) msm_stage_kernel(const uint16_t* __restrict__ digits, MsmShape sh, const uint32_t* __restrict__ blockoff,
+                                                         const uint32_t* __restrict__ wg_total, const uint32_t* __restrict__ region_base,
+                                                         uint32_t nblocks, uint32_t* __restrict__ stage_idx, uint16_t* __restrict__ stage_low) {
+    ZK_DYN_SHARED(uint32_t, lds);
+    const uint32_t R = sh.nranges;
+    uint32_t* e_idx = lds;
+    uint32_t* starts = e_idx + MSM_SBLK;
+    uint32_t* gdst = starts + (R + 1);
+    uint32_t* lcur = gdst + R;
+    uint16_t* e_low = reinterpret_cast<uint16_t*>(lcur + R);
+    uint16_t* e_h = e_low + MSM_SBLK;
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint32_t blk = blockIdx.x % nblocks, wl = blockIdx.x / nblocks;
+    const uint32_t rb_log = 31u - (uint32_t)__clz(sh.rb);
+    // chunk sizes of this block (from the scanned block counts), their exclusive scan, their destinations
+    uint32_t size = 0;
+    if (tid < R) {
+        const uint32_t r = wl * R + tid;
+        const uint32_t off = blockoff[(uint64_t)r * nblocks + blk];
+        const uint32_t next = blk + 1 < nblocks ? blockoff[(uint64_t)r * nblocks + blk + 1] : wg_total[r];
+        size = next - off;
+        gdst[tid] = region_base[r] + off;
+        lcur[tid] = 0;
+        starts[tid + 1] = size;
+    }
+    if (tid == 0) starts[0] = 0;
+    __syncthreads();
+    for (uint32_t d = 1; d < R; d <<= 1) {   // inclusive Hillis-Steele on starts[1 .. R]
+        const uint32_t u = (tid < R && tid >= d) ? starts[tid + 1 - d] : 0;
+        __syncthreads();
+        if (tid < R) starts[tid + 1] += u;
+        __syncthreads();
+    }
+    const uint16_t* row = digits + (uint64_t)wl * sh.n;
+    for (uint32_t k = tid; k < MSM_SBLK; k += nth) {
+        const uint32_t i = blk * MSM_SBLK + k;
+        if (i >= sh.n) break;
+        bool neg;
+        const uint32_t mag = digit_mag(row[i], neg);
+        if (mag != 0) {
+            const uint32_t b = mag - 1, h = b >> rb_log;
+            const uint32_t pos = starts[h] + atomicAdd(&lcur[h], 1u);
+            e_idx[pos] = i | (neg ? 0x80000000u : 0u);
+            e_low[pos] = (uint16_t)(b & (sh.rb - 1));
+            e_h[pos] = (uint16_t)h;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = starts[R];
+    for (uint32_t k = tid; k < total; k += nth) {
+        const uint32_t h = e_h[k];
+        const uint32_t d = gdst[h] + (k - starts[h]);
+        stage_idx[d] = e_idx[k];
+        stage_low[d] = e_low[k];
+    }
+}
+
+// grid = regions; workgroup (w, h) owns buckets [h*rb, (h+1)*rb) of window w and entries [region_base, + wg_total) of the
+// staged and of the sorted array.  LDS: hist[rb] | cur[rb] | part[1024] | bins[258] | perm[cap] (u16).
+// A region of at most `cap` entries is sorted inside LDS -- as a permutation of its entry numbers, 2 bytes each -- and
+// written out as one coalesced stream (sorted[k] = staged[perm[k]], the gather served by L2); scattering 4-byte stores
+// over the region directly, as an oversized region (a skewed witness) still does, costs ~5x the HBM write traffic.
+template <class Tag>
+__global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t* __restrict__ stage_idx, const uint16_t* __restrict__ stage_low,
+                                                        MsmShape sh, const uint32_t* __restrict__ region_base,
+                                                        const uint32_t* __restrict__ wg_total, uint32_t* __restrict__ counts,
+                                                        uint32_t* __restrict__ offs, uint32_t* __restrict__ order,
+                                                        uint32_t* __restrict__ sorted, uint32_t cap) {
+    ZK_DYN_SHARED(uint32_t, lds);
+    uint32_t* hist = lds;
+    uint32_t* cur = hist + sh.rb;
+    uint32_t* part = cur + sh.rb;
+    uint32_t* bins = part + 1024;
+    uint16_t* perm = reinterpret_cast<uint16_t*>(bins + 258);
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint32_t w = blockIdx.x / sh.nranges, h = blockIdx.x % sh.nranges;
+    const uint64_t gb0 = (uint64_t)w * sh.nbk + (uint64_t)h * sh.rb;
+    const uint32_t base = region_base[blockIdx.x], total = wg_total[blockIdx.x];
+    const bool local = total <= cap;   // cap <= 65536: entry numbers fit a u16
+    for (uint32_t j = tid; j < sh.rb; j += nth) hist[j] = 0;
+    for (uint32_t j = tid; j < 258; j += nth) bins[j] = 0;
+    __syncthreads();
+    for (uint32_t e = tid; e < total; e += nth) atomicAdd(&hist[stage_low[base + e]], 1u);
     __syncthreads();
     // exclusive scan of this range's counts: per-lane chunk sums, Hillis-Steele over the lanes, then refill
     const uint32_t per = (sh.rb + nth - 1) / nth;
     const uint32_t jlo = tid * per < sh.rb ? tid * per : sh.rb;
     const uint32_t jhi = jlo + per < sh.rb ? jlo + per : sh.rb;
     uint32_t sum = 0;
-    for (uint32_t j = jlo; j < jhi; j++) sum += counts[gb0 + j];
+    for (uint32_t j = jlo; j < jhi; j++) sum += hist[j];
     part[tid] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < nth; d <<= 1) {
@@ -170,36 +261,48 @@ __global__ void __launch_bounds__(1024) msm_scatter_kernel(const uint16_t* __res
         part[tid] += v;
         __syncthreads();
     }
-    uint32_t run = base + part[tid] - sum;
+    uint32_t run = part[tid] - sum;   // position inside the region
     for (uint32_t j = jlo; j < jhi; j++) {
-        const uint32_t cnt = counts[gb0 + j];
+        const uint32_t cnt = hist[j];
         cur[j] = run;
-        offs[gb0 + j] = run;
+        offs[gb0 + j] = base + run;
+        counts[gb0 + j] = cnt;
         run += cnt;
         atomicAdd(&bins[255u - (cnt < 255u ? cnt : 255u)], 1u);  // size classes, largest first
     }
     __syncthreads();
     // order[]: the buckets of this range sorted by descending size class, so that the 64 buckets a wave of the
-    // accumulate kernel works on have (nearly) equal lengths
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < 256; k++) {
-            const uint32_t v = bins[k];
-            bins[k] = acc;
-            acc += v;
-        }
+    // accumulate kernel works on have (nearly) equal lengths.  Exclusive scan of the 256 class counts first.
+    const uint32_t bv = tid < 256 ? bins[tid] : 0;
+    part[tid] = bv;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t v = (tid >= d && tid < 256) ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
     }
+    if (tid < 256) bins[tid] = part[tid] - bv;
     __syncthreads();
     for (uint32_t j = jlo; j < jhi; j++) {
-        const uint32_t cnt = counts[gb0 + j];
+        const uint32_t cnt = hist[j];
         const uint32_t r = atomicAdd(&bins[255u - (cnt < 255u ? cnt : 255u)], 1u);
         order[gb0 + r] = (uint32_t)(gb0 + j);
     }
-    // scatter
-    for_digits_in_range(digits + (uint64_t)w * sh.n_pad, sh.n_pad, lo, sh.rb, [&](uint32_t i, uint32_t j, bool neg) {
-        const uint32_t p = atomicAdd(&cur[j], 1u);
-        sorted[p] = i | (neg ? 0x80000000u : 0u);
-    });
+    // counting-sort scatter through the LDS cursors
+    if (local) {
+        for (uint32_t e = tid; e < total; e += nth) {
+            const uint32_t p = atomicAdd(&cur[stage_low[base + e]], 1u);
+            perm[p] = (uint16_t)e;
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < total; k += nth) sorted[base + k] = stage_idx[base + perm[k]];
+    } else {
+        for (uint32_t e = tid; e < total; e += nth) {
+            const uint32_t p = atomicAdd(&cur[stage_low[base + e]], 1u);
+            sorted[base + p] = stage_idx[base + e];
+        }
+    }
 }
 
 // Bucket accumulation: persistent waves pulling 64-bucket tasks from a queue, largest size class first
@@ -242,6 +345,9 @@ __device__ __forceinline__ void accumulate_slice(XYZZ<C>& acc, const Affine<C>* 
 // are visited largest size class first (rank-major over the per-range size-sorted lists), so the queue drains
 // into the shortest buckets and all SIMDs finish together; lanes never wait for a longer neighbour.
 constexpr uint32_t MSM_BATCH = 64;
+// Visiting order: rank-major over the per-range size-sorted bucket lists, MSM_RANKW buckets of a range at a time.  The
+// narrower the rank, the closer the order is to globally largest-first (512-bucket ranges: 32 ranks).
+constexpr uint32_t MSM_RANKW = 16;
 
 template <class C>
 __global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
@@ -250,9 +356,9 @@ __global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __r
                                       MsmQueue* __restrict__ q, MsmSeg* __restrict__ seg_list, uint32_t* __restrict__ big_list) {
     __shared__ uint32_t s_next, s_end;
     const uint32_t nrt = (uint32_t)sh.nw * sh.nranges;                 // ranges in this call
-    const uint32_t per_rank = nrt * 64;                                // bucket positions per size rank
+    const uint32_t per_rank = nrt * MSM_RANKW;                         // bucket positions per size rank
     const uint32_t S = 1u << sh.split_log;                             // pieces per bucket
-    const uint32_t total = (((sh.rb + 63) / 64) * per_rank) << sh.split_log;   // visiting positions (ranges padded to 64 slots)
+    const uint32_t total = (((sh.rb + MSM_RANKW - 1) / MSM_RANKW) * per_rank) << sh.split_log;   // visiting positions (ranges padded to whole ranks)
     const uint32_t lane = threadIdx.x;
     if (lane == 0) {
         s_next = 0;
@@ -271,7 +377,7 @@ __global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __r
             if (i < s_end) {
                 const uint32_t ib = i >> sh.split_log, piece = i & (S - 1);
                 const uint32_t r = ib / per_rank, rem = ib % per_rank;
-                const uint32_t g = rem / 64, slot = r * 64 + (rem % 64);
+                const uint32_t g = rem / MSM_RANKW, slot = r * MSM_RANKW + (rem % MSM_RANKW);
                 if (slot < sh.rb) {
                     const uint32_t gb = order[(uint64_t)g * sh.rb + slot];
                     const uint32_t cnt = counts[gb];

@@ -74,11 +74,13 @@ typedef struct {
     int reserved;
 } zk_msm_opts;
 
-/* Wall-clock of the phases of the last zk_msm* call on this process (milliseconds, HIP events). */
+/* Wall-clock of the phases of the last zk_msm* call on this process (milliseconds, HIP events).
+ * The sort has three phases: digits_ms = digit counts per (scalar block, window, bucket range) + their scans,
+ * hist_ms = staging the digits range by range, scatter_ms = the per-range LDS histogram / counting-sort scatter. */
 typedef struct {
     float digits_ms, hist_ms, scatter_ms, accumulate_ms, reduce_ms, host_tail_ms, total_ms;
     int window_bits, windows_total, windows_done;
-    int groups;      /* window groups pipelined on two streams (phase times above are summed over groups, total_ms is wall) */
+    int groups;      /* always 1 (a two-stream window-group pipeline was measured slower and removed) */
     int limb_bits;   /* bucket arithmetic of the call: 32 = saturated words (G2), 29 = lazy unsaturated limbs (G1: 9 x 29 bits, BLS12-381 14 x 28) */
 } zk_msm_profile;
 

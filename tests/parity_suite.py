@@ -301,26 +301,22 @@ def check_witness_map(zk, name, logm, threads=8):
     assert (h2 == exp2).all()
 
 
-def check_msm_groups(zk, cname, n, window_bits):
-    """the window-group pipeline (two streams) gives the same point for every group count, sharded or not"""
+def check_msm_sort_shapes(zk, cname, n, window_bits_list):
+    """the staged sort (count / stage by bucket range / LDS counting sort per region) for several window widths --
+    one range per window, several ranges, several scalar blocks -- on a skewed witness, whole and window-sharded"""
     pts = bases_for(cname, n)
     sc = scalars_for(cname, n, 41, realistic=True)
     exp = orc.msm_ark(cname, pts, sc, threads=8)
     bases = zk.Bases(cname, pts)
-    W = zk.msm_window_count(cname, n, window_bits)
-    try:
-        for groups in (1, 2, 3, 5, 8):
-            os.environ["ZK_MSM_GROUPS"] = str(groups)
-            got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
-            assert (got == exp).all(), (cname, groups)
-            assert zk.msm_last_profile()["groups"] == min(groups, W)
-            lo = zk.msm(bases, sc, window_bits=window_bits, windows=(0, W // 2))
-            hi = zk.msm(bases, sc, window_bits=window_bits, windows=(W // 2, W))
-            assert (affine_of(zk, cname, zk.point_add(cname, lo, hi)) == exp).all(), (cname, groups, "sharded")
-    finally:
-        os.environ.pop("ZK_MSM_GROUPS", None)
+    for window_bits in window_bits_list:
+        W = zk.msm_window_count(cname, n, window_bits)
+        got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
+        assert (got == exp).all(), (cname, window_bits)
+        assert zk.msm_last_profile()["groups"] == 1
+        lo = zk.msm(bases, sc, window_bits=window_bits, windows=(0, W // 3))
+        hi = zk.msm(bases, sc, window_bits=window_bits, windows=(W // 3, W))
+        assert (affine_of(zk, cname, zk.point_add(cname, lo, hi)) == exp).all(), (cname, window_bits, "sharded")
     bases.free()
-
 
 def check_ntt_fused_coset(zk, name, logn, threads=8):
     """zk_ntt_coset_device: the coset shifts fused into the first / last NTT pass (on-the-fly powers from two small

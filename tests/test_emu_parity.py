@@ -79,9 +79,9 @@ def test_vec_ops_and_witness_map(zk):
     ps.check_witness_map(zk, "Bn254Fr", 4)
 
 
-def test_msm_window_groups(zk):
-    ps.check_msm_groups(zk, "Vesta", 200, 5)
-    ps.check_msm_groups(zk, "Bls381G1", 90, 7)
+def test_msm_sort_shapes(zk):
+    ps.check_msm_sort_shapes(zk, "Vesta", 2100, (5, 13))        # 3 scalar blocks; 1 and 2 ranges per window
+    ps.check_msm_sort_shapes(zk, "Bls381G1", 90, (7,))
 
 
 def test_ntt_fused_coset(zk, monkeypatch):

@@ -114,9 +114,9 @@ def test_msm_big_buckets(zk, cname):
 
 
 @pytest.mark.parametrize("cname", ["Vesta", "Bn254G1", "Bls381G1", "Bls381G2"])
-def test_msm_window_groups(zk, cname):
-    ps.check_msm_groups(zk, cname, 1 << 13, 0)
-    ps.check_msm_groups(zk, cname, 70000, 16)      # the default plan switches the pipeline on from 2^16 points
+def test_msm_sort_shapes(zk, cname):
+    ps.check_msm_sort_shapes(zk, cname, 1 << 13, (0, 9))
+    ps.check_msm_sort_shapes(zk, cname, 70000, (16, 14, 12))   # 16 / 4 / 1 bucket ranges per window, 69 scalar blocks
 
 
 @pytest.mark.parametrize("cname", ["Vesta", "Bn254G1", "Bls381G1", "Bn254G2"])

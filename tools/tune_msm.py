@@ -24,7 +24,7 @@ grid = {"ZK_MSM_SPLIT": ["0", "1"], "ZK_MSM_C": ["16", "15"], "ZK_MSM_SLICE": ["
 if os.environ.get("TUNE_GRID"):   # e.g. TUNE_GRID='{"ZK_MSM_SLICE": ["2", "4"]}'
     import json
     grid = json.loads(os.environ["TUNE_GRID"])
-base = {"ZK_MSM_C": "16", "ZK_MSM_SLICE": "8", "ZK_MSM_WAVES": "3", "ZK_MSM_GROUPS": "1", "ZK_MSM_SPLIT": "1"}
+base = {"ZK_MSM_C": "16", "ZK_MSM_SLICE": "8", "ZK_MSM_WAVES": "3", "ZK_MSM_SPLIT": "1"}
 configs = [dict(base)]
 for k, vals in grid.items():
     for v in vals:
