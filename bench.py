@@ -34,9 +34,11 @@ def main():
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--realistic", action="store_true", help="0/1-heavy witness mix (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="column", choices=["column", "halo2"],
+    ap.add_argument("--workload", default="column", choices=["column", "halo2", "groth16"],
                     help="column: BASELINE configs[1] (default, the headline). halo2: the synthetic 2^20-row halo2 GPU work-list "
-                         "of SURVEY 8d / configs[2]: 13 advice commits (MSM) + 13 iNTT(2^k) + 13 extended NTT(2^(k+3)) + 1 extended iNTT")
+                         "of SURVEY 8d / configs[2]: 13 advice commits (MSM) + 13 iNTT(2^k) + 13 extended NTT(2^(k+3)) + 1 extended iNTT. "
+                         "groth16: the GPU work of one Groth16 proof at domain size 2^logn (SURVEY 8d 'Config 4'): witness_map (7 NTTs) + "
+                         "4 G1 MSMs + 1 G2 MSM; --curve Bn254G1 or Bls381G1 picks the pairing family")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,6 +74,8 @@ def main():
     zk.load()
     zk.init(local_rank)
     curve = args.curve
+    if args.workload == "groth16":
+        return bench_groth16(args, zk, zkdist, ps, pyref, torch, dist, np, world, rank, torch.cuda.current_stream().cuda_stream)
     sfield = pyref.CURVES[curve][1]               # scalar field of the MSM == field of the NTT
     n = 1 << args.logn
     nl = zk.base_limbs(curve)
@@ -241,6 +245,93 @@ def bench_halo2(args, zk, zkdist, ps, torch, dist, np, curve, sfield, n, bases, 
             "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery integers)", "data": "synthetic",
             "config": {"workload": "synthetic halo2 GPU work-list, 2^%d rows: 13 x (%s MSM + iNTT 2^%d + coset NTT 2^%d) + 1 iNTT 2^%d"
                                    % (k, curve, k, ext, ext), "rows_per_step": n, "parallelism": "msm-window-shard x%d" % world}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_groth16(args, zk, zkdist, ps, pyref, torch, dist, np, world, rank, st):
+    """GPU work of ONE Groth16 proof (ark-groth16 0.3 create_proof, SURVEY 3.6 / 8d 'Config 4') at domain size m = 2^logn:
+    R1CStoQAP::witness_map (3 iFFT + 3 coset FFT + pointwise + 1 coset iFFT, all resident) -> h; then the five MSMs
+    h_query.h (m - 1, scalars straight from the NTT output, Montgomery form), a_query.z, b_g1_query.z (m), l_query.aux
+    (0.75 m) on G1 and b_g2_query.z (m) on G2.  Synthetic SRS: seeded points P_i = [k_i]G, one array per query vector;
+    witness z with the 0/1-heavy mix of a real assignment.  R1CS synthesis, the sparse matrix-vector products that make
+    a/b/c, and the final few point operations stay on the CPU (not part of this line).  N > 1: every MSM is
+    window-sharded over the ranks; the witness map runs on rank 0."""
+    fam = "Bn254" if args.curve.startswith("Bn254") else "Bls381"
+    g1, g2, fr = fam + "G1", fam + "G2", fam + "Fr"
+    m = 1 << args.logn
+    n_l = (3 * m) // 4
+
+    def make_bases(curve, n, seed):
+        ks = ps.scalars_for(curve, n, seed)
+        d = torch.empty((n, 2 * zk.base_limbs(curve)), dtype=torch.int64, device="cuda")
+        zk.fixed_base_mul_device(curve, torch.from_numpy(ks.view(np.int64)).cuda(), d, n, stream=st)
+        torch.cuda.synchronize()
+        return zk.Bases(curve, device_tensor=d, n=n)
+
+    t_setup = time.perf_counter()
+    a_query, b_g1_query = make_bases(g1, m, 0xA11), make_bases(g1, m, 0xB11)
+    h_query, l_query = make_bases(g1, m - 1, 0xC11), make_bases(g1, n_l, 0xD11)
+    b_g2_query = make_bases(g2, m, 0xE11)
+    t_setup = time.perf_counter() - t_setup
+    z = torch.from_numpy(ps.scalars_for(g1, m, 0xC0DE, realistic=True).view(np.int64)).cuda()     # full assignment, canonical
+    z_aux = z[:n_l].contiguous()
+    abc_host = [ps.rand_field(fr, m, 0xF00D + i) for i in range(3)]
+    d_abc0 = [torch.from_numpy(x.view(np.int64)).cuda() for x in abc_host]
+    d_abc = [torch.empty_like(x) for x in d_abc0]
+    phases = {"witness_map_ms": 0.0, "msm_h_ms": 0.0, "msm_a_ms": 0.0, "msm_b_g1_ms": 0.0, "msm_l_ms": 0.0, "msm_b_g2_ms": 0.0}
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def step(timed):
+        for dst, src in zip(d_abc, d_abc0):
+            dst.copy_(src)                                   # fresh evaluation vectors (the map works in place)
+        if rank == 0:
+            evs[0].record()
+            zk.groth16_witness_map(fr, d_abc[0], d_abc[1], d_abc[2], stream=st)
+            evs[1].record()
+        torch.cuda.synchronize()                             # phase attribution: the h MSM must not absorb the map's time
+        if world > 1:
+            dist.broadcast(d_abc[0], src=0)
+        jobs = (("msm_h_ms", h_query, d_abc[0][:m - 1], True), ("msm_a_ms", a_query, z, False), ("msm_b_g1_ms", b_g1_query, z, False),
+                ("msm_l_ms", l_query, z_aux, False), ("msm_b_g2_ms", b_g2_query, z, False))
+        for name, bases, sc, mont in jobs:
+            t0 = time.perf_counter()
+            zkdist.msm_sharded(bases, sc, montgomery=mont, window_bits=args.window_bits, stream=st)
+            if timed:
+                phases[name] += (time.perf_counter() - t0) * 1e3
+        if timed and rank == 0:
+            torch.cuda.synchronize()
+            phases["witness_map_ms"] += evs[0].elapsed_time(evs[1])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "constraints/sec", "value": m * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (Montgomery integers; G1 buckets on lazy 29/28-bit limbs, G2 on 32-bit words)",
+            "data": "synthetic",
+            "config": {"workload": "Groth16 prover GPU work, domain 2^%d over %s: witness_map (7 NTTs) + MSMs h (m-1), a, b_g1 (m), l (0.75 m) on G1 + b_g2 (m) on G2"
+                                   % (args.logn, fam), "rows_per_step": m, "parallelism": "msm-window-shard x%d" % world,
+                       "srs_setup_s": t_setup},
+            "phases_ms": {k: v / args.steps for k, v in phases.items()}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
