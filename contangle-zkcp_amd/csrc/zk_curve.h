@@ -19,10 +19,11 @@
 
 namespace zk {
 
-// EXT: 1 = Fq, 2 = Fq2, 29 = the lazy 9 x 29-bit view of Fq used by the MSM bucket kernels (zk_curve29.h)
+// EXT: 1 = Fq, 2 = Fq2; 29 / 58 = the lazy-limb views of Fq / Fq2 used by the MSM bucket kernels (zk_curve29.h)
 template <class C>
 using Coord = std::conditional_t<C::EXT == 29, Fe29<typename C::Fq>,
-                                 std::conditional_t<C::EXT == 2, Fe2<typename C::Fq>, Fe<typename C::Fq>>>;
+                                 std::conditional_t<C::EXT == 58, Fe29x2<typename C::Fq>,
+                                                    std::conditional_t<C::EXT == 2, Fe2<typename C::Fq>, Fe<typename C::Fq>>>>;
 template <class C>
 constexpr int coord_words() {
     return C::EXT * C::Fq::N;

@@ -58,9 +58,11 @@ ZK_HD void fe29_cmov(Fe29<P>& r, const Fe29<P>& a, bool sel) {
     for (int i = 0; i < F29<P>::L; i++) r.v[i] = sel ? a.v[i] : r.v[i];
 }
 
-// Montgomery product, R' = 2^261, carry-free columns (finely integrated product scanning)
-template <class P>
-ZK_HD void fe29_mul(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b) {
+// Montgomery product, R' = 2^261, carry-free columns (finely integrated product scanning).
+// TWO: r = (a b + c d) / R' -- both products summed in the same columns, one reduction (the Fq2 product below); requires
+// L (LB(a) LB(b) + LB(c) LB(d)) + L 2^(2W) + 2^36 < 2^64.
+template <class P, bool TWO>
+ZK_HD void fe29_mul_impl(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b, const Fe29<P>& c, const Fe29<P>& d) {
     using K = F29<P>;
     constexpr int L = K::L, W = K::W;
     constexpr uint32_t MASK = (1u << W) - 1;
@@ -72,7 +74,10 @@ ZK_HD void fe29_mul(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b) {
         ZK_UNROLL
         for (int i = 0; i < L; i++) {
             const int j = k - i;
-            if (j >= 0 && j < L) acc += (uint64_t)a.v[i] * b.v[j];
+            if (j >= 0 && j < L) {
+                acc += (uint64_t)a.v[i] * b.v[j];
+                if (TWO) acc += (uint64_t)c.v[i] * d.v[j];
+            }
         }
         ZK_UNROLL
         for (int i = 0; i < L; i++) {
@@ -92,6 +97,14 @@ ZK_HD void fe29_mul(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b) {
     out[L - 1] = (uint32_t)acc;
     ZK_UNROLL
     for (int i = 0; i < L; i++) r.v[i] = out[i];
+}
+template <class P>
+ZK_HD void fe29_mul(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b) {
+    fe29_mul_impl<P, false>(r, a, b, a, b);
+}
+template <class P>
+ZK_HD void fe29_mulacc(Fe29<P>& r, const Fe29<P>& a, const Fe29<P>& b, const Fe29<P>& c, const Fe29<P>& d) {
+    fe29_mul_impl<P, true>(r, a, b, c, d);
 }
 template <class P>
 ZK_HD void fe29_sqr(Fe29<P>& r, const Fe29<P>& a) {
@@ -239,6 +252,112 @@ ZK_HD void fe29_to_std(Fe<P>& r, const Fe29<P>& a) {
     fe29_mul(t, t, c);
     fe29_canon(t, t);
     fe29_pack(r, t);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fq2 = Fq[u] / (u^2 + 1) over the lazy limbs (the G2 twists of BN254 and BLS12-381): a pair of Fe29.  The product is
+//   c0 = (a0 b0 + a1 (k p - b1)) / R'      c1 = (a0 b1 + a1 b0) / R'
+// two double products with ONE reduction each (2 x (2 L^2 + reduction) MADs instead of the 3 full products of Karatsuba
+// plus its biased recombination), and its outputs are strict limbs with a value of a few p at most -- which is what lets
+// the G2 formulas of zk_curve29.h keep the bias constants of the G1 ones.  `negbias` is the BIAS table used to negate b.c1:
+// it must dominate b.c1 (see fe29_sub).  The square is the complex one, (a0 + a1)(a0 - a1 + k p) and 2 a0 a1.
+// ------------------------------------------------------------------------------------------------------------------
+template <class P>
+struct alignas(4) Fe29x2 {
+    Fe29<P> c0, c1;
+};
+template <class P>
+ZK_HD void fe29_zero(Fe29x2<P>& r) {
+    fe29_zero(r.c0);
+    fe29_zero(r.c1);
+}
+template <class P>
+ZK_HD void fe29_one(Fe29x2<P>& r) {
+    fe29_one(r.c0);
+    fe29_zero(r.c1);
+}
+template <class P>
+ZK_HD bool fe29_is_literal_zero(const Fe29x2<P>& a) {
+    return fe29_is_literal_zero(a.c0) && fe29_is_literal_zero(a.c1);
+}
+template <class P>
+ZK_HD void fe29_cmov(Fe29x2<P>& r, const Fe29x2<P>& a, bool sel) {
+    fe29_cmov(r.c0, a.c0, sel);
+    fe29_cmov(r.c1, a.c1, sel);
+}
+template <class P>
+ZK_HD void fe29_add(Fe29x2<P>& r, const Fe29x2<P>& a, const Fe29x2<P>& b) {
+    fe29_add(r.c0, a.c0, b.c0);
+    fe29_add(r.c1, a.c1, b.c1);
+}
+template <class P>
+ZK_HD void fe29_sub(Fe29x2<P>& r, const Fe29x2<P>& a, const Fe29x2<P>& b, const uint32_t (&bias)[F29<P>::L]) {
+    fe29_sub(r.c0, a.c0, b.c0, bias);
+    fe29_sub(r.c1, a.c1, b.c1, bias);
+}
+template <class P>
+ZK_HD void fe29_sub3(Fe29x2<P>& r, const Fe29x2<P>& a, const Fe29x2<P>& b, const Fe29x2<P>& c) {
+    fe29_sub3(r.c0, a.c0, b.c0, c.c0);
+    fe29_sub3(r.c1, a.c1, b.c1, c.c1);
+}
+template <class P>
+ZK_HD void fe29_sub2x(Fe29x2<P>& r, const Fe29x2<P>& a, const Fe29x2<P>& c) {
+    fe29_sub2x(r.c0, a.c0, c.c0);
+    fe29_sub2x(r.c1, a.c1, c.c1);
+}
+template <class P>
+ZK_HD void fe29_norm(Fe29x2<P>& r, const Fe29x2<P>& a) {
+    fe29_norm(r.c0, a.c0);
+    fe29_norm(r.c1, a.c1);
+}
+template <class P>
+ZK_HD void fe29_mul(Fe29x2<P>& r, const Fe29x2<P>& a, const Fe29x2<P>& b, const uint32_t (&negbias)[F29<P>::L]) {
+    Fe29<P> z, nb1, t0, t1;
+    fe29_zero(z);
+    fe29_sub(nb1, z, b.c1, negbias);
+    fe29_norm(nb1, nb1);
+    fe29_mulacc(t0, a.c0, b.c0, a.c1, nb1);
+    fe29_mulacc(t1, a.c0, b.c1, a.c1, b.c0);
+    r.c0 = t0;
+    r.c1 = t1;
+}
+template <class P>
+ZK_HD void fe29_sqr(Fe29x2<P>& r, const Fe29x2<P>& a, const uint32_t (&dbias)[F29<P>::L]) {
+    Fe29<P> s, d, e, t0, t1;
+    fe29_add(s, a.c0, a.c1);
+    fe29_sub(d, a.c0, a.c1, dbias);
+    fe29_norm(d, d);
+    fe29_add(e, a.c0, a.c0);
+    fe29_mul(t0, s, d);
+    fe29_mul(t1, e, a.c1);
+    r.c0 = t0;
+    r.c1 = t1;
+}
+// value-preserving contraction: a * (R' mod p) / R' = a, strict limbs, value < VB(a) / 2^7 + 1 times p
+template <class P>
+ZK_HD void fe29_refresh(Fe29x2<P>& r, const Fe29x2<P>& a) {
+    Fe29<P> one;
+    fe29_one(one);
+    fe29_mul(r.c0, a.c0, one);
+    fe29_mul(r.c1, a.c1, one);
+}
+// is the Fq2 value zero, given that both components are integers in [kmin p, kmax p]?
+template <class P>
+ZK_HD bool fe29_is_zero_mod_p(const Fe29x2<P>& a, uint32_t kmin, uint32_t kmax) {
+    uint32_t k0, k1;
+    if (!fe29_zero_filter(a.c0, kmin, kmax, k0)) return false;
+    if (!fe29_zero_filter(a.c1, kmin, kmax, k1)) return false;
+    return fe29_is_kp(a.c0, k0) && fe29_is_kp(a.c1, k1);
+}
+template <class P>
+ZK_HD void fe29_from_std(Fe29x2<P>& r, const Fe2<P>& a) {
+    fe29_from_std(r.c0, a.c0);
+    fe29_from_std(r.c1, a.c1);
+}
+template <class P>
+ZK_HD void fe29_to_std(Fe2<P>& r, const Fe29x2<P>& a) {
+    fe29_to_std(r.c0, a.c0);
+    fe29_to_std(r.c1, a.c1);
 }
 
 }  // namespace zk

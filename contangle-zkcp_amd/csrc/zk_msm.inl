@@ -19,6 +19,10 @@ template <class C>
 inline void partial_to_std(XYZZ<C>& r, const XYZZ<C29<C>>& p) {
     xyzz29_to_std<C>(r, p);
 }
+template <class C>
+inline void partial_to_std(XYZZ<C>& r, const XYZZ<C29x2<C>>& p) {
+    xyzz29_to_std<C>(r, p);
+}
 
 // C: the curve of the ABI call.  CK: the view the kernels compute in.  bases: device array of Affine<CK>.
 template <class C, class CK>
@@ -39,7 +43,7 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
     g.prof.window_bits = c;
     g.prof.windows_total = nwin;
     g.prof.windows_done = w1 - w0;
-    g.prof.limb_bits = CK::EXT == 29 ? 29 : 32;
+    g.prof.limb_bits = CK::EXT >= 29 ? 29 : 32;
     if (n > 0 && w1 > w0) {
         if (n >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
         MsmShape sh;
@@ -137,7 +141,7 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
             g.have_events = true;
         }
         // resident waves per SIMD: the F29 kernel holds 138 VGPRs (3 fit), the 32-bit one 119 (4 fit); tools/tune_msm.py
-        unsigned waves_per_simd = CK::EXT == 29 ? 3 : 4;
+        unsigned waves_per_simd = CK::EXT == 29 ? 3 : (CK::EXT == 58 ? 2 : 4);
         if (const char* e = getenv("ZK_MSM_WAVES")) {
             int v = atoi(e);
             if (v >= 1 && v <= 8) waves_per_simd = (unsigned)v;
@@ -234,11 +238,11 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
 }
 
 
-// the G1 curves (Pallas, Vesta, BN254 G1: 9 x 29-bit limbs; BLS12-381 G1: 14 x 28) run their bucket arithmetic in the
-// lazy-limb view
+// every curve runs its bucket arithmetic in the lazy-limb view (Pallas, Vesta, BN254: 9 x 29-bit limbs; BLS12-381: 14 x 28;
+// G2 as pairs of those); ZK_MSM_F29=0 forces the saturated 32-bit path
 template <class C>
 constexpr bool has_f29() {
-    return C::EXT == 1;
+    return C::EXT == 1 || C::EXT == 2;
 }
 inline bool f29_enabled() {
     const char* e = getenv("ZK_MSM_F29");   // "0" forces the saturated 32-bit path (A/B measurements, tests)
@@ -251,9 +255,9 @@ int bases_prepare_run(BasesEntry& be) {
     if constexpr (has_f29<C>()) {
         if (be.n == 0) return ZK_OK;
         void* d = nullptr;
-        HIP_TRY(hipMalloc(&d, sizeof(Affine<C29<C>>) * be.n));
+        HIP_TRY(hipMalloc(&d, sizeof(Affine<F29View<C>>) * be.n));
         ZK_LAUNCH((bases_to29_kernel<C>), (unsigned)((be.n + 255) / 256), 256, 0, (hipStream_t)0, (const Affine<C>*)be.dev,
-                  (Affine<C29<C>>*)d, be.n);
+                  (Affine<F29View<C>>*)d, be.n);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess) {
             hipFree(d);
             return ZK_ERR_HIP;
@@ -268,7 +272,7 @@ int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t 
             void* out_jac, hipStream_t st) {
     if constexpr (has_f29<C>()) {
         if (be.dev29 && f29_enabled())
-            return msm_run_impl<C, C29<C>>((const Affine<C29<C>>*)be.dev29, d_scalars, n, mont, opts, out_jac, st);
+            return msm_run_impl<C, F29View<C>>((const Affine<F29View<C>>*)be.dev29, d_scalars, n, mont, opts, out_jac, st);
     }
     return msm_run_impl<C, C>((const Affine<C>*)be.dev, d_scalars, n, mont, opts, out_jac, st);
 }

@@ -637,11 +637,11 @@ __global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<C>* __restrict_
 
 // bases as uploaded (x R, 8 x u32 per coordinate)  ->  the F29 view the bucket kernels use (x R', 9 x 29-bit limbs)
 template <class C>
-__global__ void __launch_bounds__(256) bases_to29_kernel(const Affine<C>* __restrict__ in, Affine<C29<C>>* __restrict__ out, uint64_t n) {
+__global__ void __launch_bounds__(256) bases_to29_kernel(const Affine<C>* __restrict__ in, Affine<F29View<C>>* __restrict__ out, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<C> p = in[i];
-    Affine<C29<C>> q;
+    Affine<F29View<C>> q;
     aff29_from_std(q, p);
     out[i] = q;
 }

@@ -166,7 +166,7 @@ def check_msm_vs_oracle(zk, cname, n, window_bits=0, realistic=False, seed=5, th
     got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
     assert (got == exp).all(), (cname, n, window_bits, realistic)
     assert orc.on_curve(cname, got)
-    lazy = cname in ("Pallas", "Vesta", "Bn254G1", "Bls381G1")   # G1 buckets run on lazy limbs (9 x 29 bits; 14 x 28 for BLS12-381)
+    lazy = True   # buckets run on lazy limbs (9 x 29 bits; 14 x 28 for BLS12-381; pairs of those on the G2 twists)
     assert zk.msm_last_profile()["limb_bits"] == (29 if lazy and os.environ.get("ZK_MSM_F29") != "0" else 32)
     if lazy:                                                  # and must agree with the saturated 32-bit path
         os.environ["ZK_MSM_F29"] = "0"

@@ -180,3 +180,63 @@ def test_f29_conversion_and_zero_filter(field):
     res = run(lines)
     for r, e in zip(res, exp):
         assert bool(r[2]) == e
+
+
+@pytest.mark.parametrize("field", ["Bn254Fq", "Bls381Fq"])
+def test_f29_fq2_mul_sqr_extremes(field):
+    """Fe29x2 (the G2 coordinates): product with a negated operand and one reduction per component, complex square,
+    refresh, zero test -- at the limb / value bounds tools/check_f29_bounds.py allows at their call sites"""
+    shape(field)
+    p = pyref.FIELDS[field][0]
+    Rp = 1 << (W * L)
+    rng = random.Random(58)
+    nplus = MASK + (1 << (32 - W)) - 1
+    top = p >> (W * (L - 1))
+
+    def lazy(vb, lb):
+        return spread_random(rng, rng.randrange(int(vb * p)), lb)
+
+    lines, exp = [], []
+    for op, bvb, blb, kmul in (("x2mul4k1", 2.9, MASK, 4), ("x2mul8k2", 6.9, nplus, 8), ("x2mul16k2", 14.9, nplus, 16)):
+        for k in range(60):
+            if k == 0:       # every limb at its maximum
+                a0 = a1 = b0 = [nplus] * (L - 1) + [10 * top]
+                b1 = [blb] * (L - 1) + [int((bvb - 1) * top)]
+            else:
+                a0, a1, b0, b1 = lazy(10, nplus), lazy(10, nplus), lazy(10, nplus), lazy(bvb, blb)
+            lines.append((field, op, a0 + a1, b0 + b1))
+            exp.append(("mul", a0, a1, b0, b1, kmul))
+    for op, avb, kb in (("x2sqr8k2", 6.9, 8), ("x2sqr16k2", 14.9, 16)):
+        for k in range(60):
+            a0, a1 = ([nplus] * (L - 1) + [int((avb - 1) * top)],) * 2 if k == 0 else (lazy(avb, nplus), lazy(avb, nplus))
+            lines.append((field, op, a0 + a1, [0] * (2 * L)))
+            exp.append(("sqr", a0, a1, None, None, kb))
+    for k in range(40):
+        a0, a1 = lazy(19, nplus), lazy(19, nplus)
+        lines.append((field, "x2refresh", a0 + a1, [0] * (2 * L)))
+        exp.append(("refresh", a0, a1, None, None, 0))
+    res = run(lines)
+    for r, (kind, a0, a1, b0, b1, kb) in zip(res, exp):
+        c0, c1 = r[:L], r[L:]
+        assert all(x <= MASK for x in c0[:L - 1] + c1[:L - 1])            # strict limbs
+        A0, A1 = val(a0), val(a1)
+        if kind == "mul":
+            B0, B1 = val(b0), val(b1)
+            assert val(c0) * Rp % p == (A0 * B0 - A1 * B1) % p and val(c1) * Rp % p == (A0 * B1 + A1 * B0) % p
+            assert val(c0) < (A0 * B0 + A1 * (kb * p - B1)) // Rp + p + 1 and val(c1) < (A0 * B1 + A1 * B0) // Rp + p + 1
+        elif kind == "sqr":
+            assert val(c0) * Rp % p == (A0 * A0 - A1 * A1) % p and val(c1) * Rp % p == 2 * A0 * A1 % p
+            assert val(c0) < (A0 + A1) * (A0 - A1 + kb * p) // Rp + p + 1
+        else:
+            assert val(c0) % p == A0 % p and val(c1) % p == A1 % p and val(c0) < A0 // (1 << 6) + p + 1 and val(c0) < 2 * p
+    # zero test: both components must be multiples of p inside [kmin p, kmax p]
+    lines, exp = [], []
+    for k0 in (2, 5, 9):
+        for k1 in (2, 9):
+            for d0, d1 in ((0, 0), (1, 0), (0, 1), (p // 5, 0)):
+                x0, x1 = spread_random(rng, k0 * p + d0, 1 << 31), spread_random(rng, k1 * p + d1, 1 << 31)
+                lines.append((field, "x2iszero", x0 + x1, [2, 9] + [0] * (2 * L - 2)))
+                exp.append(d0 == 0 and d1 == 0)
+    res = run(lines)
+    for r, e in zip(res, exp):
+        assert bool(r[0]) == e

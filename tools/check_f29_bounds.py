@@ -44,7 +44,7 @@ def add(a, b, name="add"):
     return r
 
 
-BIAS = {"4K1": (4, 1), "4K2": (4, 2), "16K2": (16, 2), "8K3": (8, 3)}
+BIAS = {"4K1": (4, 1), "4K2": (4, 2), "16K2": (16, 2), "8K3": (8, 3), "8K2": (8, 2)}
 
 
 def sub(a, subtrahends, bias, name="sub"):
@@ -140,9 +140,126 @@ def check_shape(w, l, log2p_max, log2p_min):
         assert mul(norm(c), V(STRICT, 1)).vb < 2
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Fq2 (G2 twists): values are pairs; the operations mirror Fe29x2 in zk_field29.h and the C29x2 formulas of zk_curve29.h
+# ---------------------------------------------------------------------------------------------------------------
+def mulacc(a, b, c, d, name="mulacc"):
+    col = L * (a.lb * b.lb + c.lb * d.lb) + L * (1 << (2 * W)) + (1 << (64 - W + 1))
+    assert col < 1 << 64, ("column overflow", name, a, b, c, d)
+    r = V(STRICT, (a.vb * b.vb + c.vb * d.vb) * P_OVER_R + 1.0, name)
+    assert r.vb < 20, ("value too large", name, r)
+    return r
+
+
+def sub2(a, subs, bias, name="sub2"):
+    return tuple(sub(a[i], [x[i] for x in subs], bias, name) for i in (0, 1))
+
+
+def norm2(a):
+    return (norm(a[0]), norm(a[1]))
+
+
+def add2(a, b):
+    return (add(a[0], b[0]), add(a[1], b[1]))
+
+
+def mul2(a, b, negbias, name="mul2"):
+    nb1 = norm(sub(V(0, 0), [b[1]], negbias, name + ".neg"))
+    return (mulacc(a[0], b[0], a[1], nb1, name), mulacc(a[0], b[1], a[1], b[0], name))
+
+
+def sqr2(a, dbias, name="sqr2"):
+    s = add(a[0], a[1])
+    d = norm(sub(a[0], [a[1]], dbias, name + ".d"))
+    return (mul(s, d, name), mul(add(a[0], a[0]), a[1], name))
+
+
+def refresh2(a):
+    one = V(STRICT, 1)
+    return (mul(a[0], one, "refresh"), mul(a[1], one, "refresh"))
+
+
+def krange(lo_sub, hi, bias):
+    """integer range (in units of p, exclusive) of hi - lo_sub + bias, as (min k, max k) of a multiple of p inside it"""
+    mult = BIAS[bias][0]
+    lo = min(mult - c.vb for c in lo_sub)
+    hi_ = max(c.vb + mult for c in hi)
+    return int(lo) + 1, int(hi_)
+
+
+def check_shape_ext2(w, l, log2p_max, log2p_min):
+    configure(w, l, log2p_max, log2p_min)
+    print("== Fq2 over %d x %d-bit limbs" % (l, w))
+    SX, SY, SZ = 2.0, 6.9, 2.0
+
+    def P2(lb, vb):
+        return (V(lb, vb), V(lb, vb))
+
+    def stored(x, y, zz, zzz, tag):
+        # (vb is an exclusive bound on value / p, so "<=" keeps value < S p)
+        assert all(c.lb <= STRICT and c.vb <= SX for c in x), (tag, x)
+        assert all(c.lb <= NPLUS and c.vb <= SY for c in y), (tag, y)
+        assert all(c.lb <= STRICT and c.vb <= SZ for c in zz + zzz), (tag, zz, zzz)
+        print("%s ok: y < %.2f p" % (tag, max(c.vb for c in y)))
+
+    X1, Y1, ZZ1, ZZZ1 = P2(STRICT, SX), P2(NPLUS, SY), P2(STRICT, SZ), P2(STRICT, SZ)
+    qx, qy = P2(STRICT, 2), P2(NPLUS, 4)
+    ny = norm2(sub2(P2(0, 0), [P2(STRICT, 2)], "4K1"))          # aff_neg_if
+    assert all(c.lb <= NPLUS and c.vb <= 4 for c in ny)
+    stored(qx, qy, P2(STRICT, 1.01), P2(STRICT, 1.01), "first add")
+
+    def add_core(p, r, x1u, y1s, rbias, tag):
+        pp = sqr2(p, "8K2")
+        ppp = mul2(p, pp, "4K1")
+        qq = mul2(x1u, pp, "4K1")
+        rr = sqr2(r, rbias)
+        x3 = refresh2(norm2(sub2(rr, [ppp, qq, qq], "8K3")))
+        t = norm2(sub2(qq, [x3], "4K1"))
+        m1, m2 = mul2(t, r, rbias), mul2(y1s, ppp, "4K1")
+        y3 = norm2(sub2(m1, [m2], "4K1"))
+        return x3, y3, pp, ppp
+
+    # madd-2008-s
+    u2, s2 = mul2(qx, ZZ1, "4K1"), mul2(qy, ZZZ1, "4K1")
+    p, r = sub2(u2, [X1], "4K1"), sub2(s2, [Y1], "8K2")
+    assert krange(X1, u2, "4K1") == (3, 5), krange(X1, u2, "4K1")
+    assert krange(Y1, s2, "8K2") == (2, 9), krange(Y1, s2, "8K2")
+    x3, y3, pp, ppp = add_core(norm2(p), norm2(r), X1, Y1, "16K2", "madd")
+    stored(x3, y3, mul2(ZZ1, pp, "4K1"), mul2(ZZZ1, ppp, "4K1"), "madd")
+
+    # add-2008-s
+    X2, Y2, ZZ2, ZZZ2 = P2(STRICT, SX), P2(NPLUS, SY), P2(STRICT, SZ), P2(STRICT, SZ)
+    u1, u2, s1, s2 = mul2(X1, ZZ2, "4K1"), mul2(X2, ZZ1, "4K1"), mul2(Y1, ZZZ2, "4K1"), mul2(Y2, ZZZ1, "4K1")
+    p, r = sub2(u2, [u1], "4K1"), sub2(s2, [s1], "4K1")
+    assert krange(u1, u2, "4K1") == (3, 5) and krange(s1, s2, "4K1") == (3, 5)
+    x3, y3, pp, ppp = add_core(norm2(p), norm2(r), u1, s1, "8K2", "add")
+    stored(x3, y3, mul2(mul2(ZZ1, ZZ2, "4K1"), pp, "4K1"), mul2(mul2(ZZZ1, ZZZ2, "4K1"), ppp, "4K1"), "add")
+
+    # dbl-2008-s-1 / mdbl-2008-s-1
+    for tag, (x, y, zz, zzz) in (("dbl", (X1, Y1, ZZ1, ZZZ1)), ("mdbl", (qx, qy, None, None))):
+        u = norm2(add2(y, y))
+        v = sqr2(u, "16K2")
+        w_ = mul2(u, v, "4K1")
+        s = mul2(x, v, "4K1")
+        t = sqr2(x, "4K1")
+        m = norm2(add2(add2(t, t), t))
+        x3 = refresh2(norm2(sub2(sqr2(m, "4K2"), [s, s], "4K2")))
+        t = norm2(sub2(s, [x3], "4K1"))
+        m1, m2 = mul2(m, t, "8K2"), mul2(w_, y, "8K2")
+        y3 = norm2(sub2(m1, [m2], "4K1"))
+        # (mdbl: v = (2y)^2 of a possibly negated base reaches 4p on 9 x 29 limbs -- the rare same-point path refreshes it)
+        stored(x3, y3, mul2(v, zz, "4K1") if zz else refresh2(v), mul2(w_, zzz, "4K1") if zzz else w_, tag)
+
+    # conversion back: norm, multiply by FROM29, canon handles < 20 p
+    for c in (X1[0], Y1[0], ZZ1[0]):
+        assert mul(norm(c), V(STRICT, 1)).vb < 2
+
+
 def main():
     check_shape(29, 9, 254.001, 253.5)     # Pasta Fp / Fq (p = 2^254 (1 + 2^-128)), BN254 Fq (2^253.6)
     check_shape(28, 14, 380.8, 380.6)      # BLS12-381 Fq (2^380.7)
+    check_shape_ext2(29, 9, 254.001, 253.5)    # BN254 G2
+    check_shape_ext2(28, 14, 380.8, 380.6)     # BLS12-381 G2
     print("all F29 bounds hold")
     return 0
 
