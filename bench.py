@@ -148,11 +148,13 @@ def main():
         # at N ranks one launch covers windows_done/windows_total of the windows -> the same share of the bytes.
         alg_bytes = n * (32 + 2 * nl * 8) * prof["windows_done"] / prof["windows_total"]
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = valu_insts = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("msm_accumulate_kernel_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("msm_accumulate_kernel_hbm_bytes_per_launch")
+                valu_insts = tj.get("msm_accumulate_kernel_valu_wave_insts_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -182,8 +184,16 @@ def main():
         adds = n * prof["windows_done"]
         line["int_mad_roofline"] = {"achieved_tmad_s": adds * 10 * mads_per_mul / (acc_ms * 1e-3) / 1e12, "peak_tmad_s": 33.7,
                                     "mads_per_field_mul": mads_per_mul, "limb_bits": prof["limb_bits"],
-                                    "note": "mixed adds x 10 field mul x MADs/mul over accumulate time; peak = measured v_mad_u64_u32 rate"}
+                                    "note": "mixed adds x 10 field mul x MAD-equivalents per mul (L^2 for a*b + L per non-zero modulus limb for m*p; the "
+                                            "compiler turns the power-of-two limbs into shifts) over accumulate time; peak = measured v_mad_u64_u32 rate"}
         line["int_mad_roofline"]["frac"] = line["int_mad_roofline"]["achieved_tmad_s"] / 33.7
+        # third view: VALU issue slots.  Wave-instructions the kernel retires per launch (rocprofv3 SQ_INSTS_VALU of this exact
+        # configuration, profiles/traffic.json) over the measured duration, against one wave-instruction per SIMD per 4 clocks.
+        if valu_insts and curve in ("Vesta", "Pallas") and args.logn == 20 and world == 1 and not args.realistic:
+            peak = 256 * 4 * 2.4e9 / 4
+            line["valu_issue_roofline"] = {"achieved_winst_s": valu_insts / (acc_ms * 1e-3), "peak_winst_s": peak,
+                                           "frac": valu_insts / (acc_ms * 1e-3) / peak,
+                                           "note": "SQ_INSTS_VALU per launch (profiles/) / accumulate time; peak = 1024 SIMDs x 2.4 GHz / 4 clocks per wave64 VALU op"}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(curve, sfield, args.logn, d_pts, sc_host, a_host, omega, result["msm"], zk)
         print(json.dumps(line), flush=True)
