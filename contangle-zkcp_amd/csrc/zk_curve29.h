@@ -3,7 +3,7 @@
 // up the overloads below instead of the generic formulas of zk_curve.h.
 //
 // Stored-point invariant (checked for every formula by tools/check_f29_bounds.py; "N+" = limbs <= 2^29 + 6):
-//     X: N+, value < 12p      Y: N+, value < 8p      ZZ, ZZZ: strict limbs, value < 2p      identity: ZZ = literal 0
+//     X: N+, value < 12p      Y: N+, value < 8p (strict, < 4p, once it has been through a formula)      ZZ, ZZZ: strict limbs, value < 2p      identity: ZZ = literal 0
 // Affine inputs come from fe29_from_std (strict limbs, value < 2p) with y possibly negated (N+, value < 4p).
 // The formulas are the same EFD madd-2008-s / add-2008-s / dbl-2008-s-1 / mdbl-2008-s-1 as zk_curve.h; what differs is
 // where a parallel carry (fe29_norm) is inserted and which bias each subtraction uses.
@@ -66,10 +66,10 @@ ZK_HD void xyzz_dbl_affine(XYZZ<C29<C>>& r, const Affine<C29<C>>& q) {
     fe29_sub2x(x3, x3, s);   // - 2s + 4p: VB 5.1
     fe29_norm(x3, x3);
     fe29_sub(t, s, x3, K::BIAS16K2);  // VB 17.1, LB < 2^31.2
-    fe29_mul(m1, m, t);
-    fe29_mul(m2, w, q.y);
-    fe29_sub(t, m1, m2, K::BIAS4K1);
-    fe29_norm(r.y, t);
+    fe29_zero(m1);
+    fe29_sub(m2, m1, w, K::BIAS4K1);  // 4p - w
+    fe29_norm(m2, m2);
+    fe29_mulacc(r.y, m, t, m2, q.y);  // m t - w y: one reduction for both products; strict, < 2p
     r.x = x3;
     r.zz = v;
     r.zzz = w;
@@ -94,10 +94,10 @@ ZK_HD void xyzz_dbl(XYZZ<C29<C>>& p) {
     fe29_sub2x(x3, x3, s);   // VB 5.4
     fe29_norm(x3, x3);
     fe29_sub(t, s, x3, K::BIAS16K2);
-    fe29_mul(m1, m, t);      // < 1.9p
-    fe29_mul(m2, w, p.y);    // < 1.1p
-    fe29_sub(t, m1, m2, K::BIAS4K1);
-    fe29_norm(p.y, t);       // VB 5.9
+    fe29_zero(m1);
+    fe29_sub(m2, m1, w, K::BIAS4K1);   // 4p - w
+    fe29_norm(m2, m2);
+    fe29_mulacc(p.y, m, t, m2, p.y);   // m t - w y: strict, < 2.2p
     p.x = x3;
     fe29_mul(p.zz, v, p.zz);
     fe29_mul(p.zzz, w, p.zzz);
@@ -141,10 +141,10 @@ ZK_HD void xyzz_add_mixed(XYZZ<C29<C>>& acc, const Affine<C29<C>>& q) {
     fe29_sub3(t, rr, ppp, qq); // rr - ppp - 2 qq + 8p: VB 11.6
     fe29_norm(acc.x, t);
     fe29_sub(t, qq, acc.x, K::BIAS16K2);   // VB 17.4, LB < 2^31.2
-    fe29_mul(m1, r, t);        // < 3.5p
-    fe29_mul(m2, acc.y, ppp);  // < 1.1p
-    fe29_sub(t, m1, m2, K::BIAS4K1);
-    fe29_norm(acc.y, t);       // VB 7.5
+    fe29_zero(m1);
+    fe29_sub(m2, m1, acc.y, K::BIAS16K2);  // 16p - Y1
+    fe29_norm(m2, m2);
+    fe29_mulacc(acc.y, r, t, m2, ppp);     // R (Q - X3) - Y1 PPP with one reduction: strict, < 3.7p
     fe29_mul(acc.zz, acc.zz, pp);
     fe29_mul(acc.zzz, acc.zzz, ppp);
 }
@@ -182,10 +182,10 @@ ZK_HD bool xyzz_add_nodbl(XYZZ<C29<C>>& acc, const XYZZ<C29<C>>& q) {
     fe29_sub3(t, rr, ppp, qq);
     fe29_norm(acc.x, t);
     fe29_sub(t, qq, acc.x, K::BIAS16K2);
-    fe29_mul(m1, r, t);
-    fe29_mul(m2, s1, ppp);
-    fe29_sub(t, m1, m2, K::BIAS4K1);
-    fe29_norm(acc.y, t);
+    fe29_zero(m1);
+    fe29_sub(m2, m1, s1, K::BIAS4K1);      // 4p - S1
+    fe29_norm(m2, m2);
+    fe29_mulacc(acc.y, r, t, m2, ppp);     // R (Q - X3) - S1 PPP: strict
     fe29_mul(acc.zz, acc.zz, q.zz);
     fe29_mul(acc.zz, acc.zz, pp);
     fe29_mul(acc.zzz, acc.zzz, q.zzz);

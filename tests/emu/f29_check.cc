@@ -43,6 +43,12 @@ static void run(const char* op) {
     for (int i = 0; i < L; i++) scanf("%u", &a.v[i]);
     for (int i = 0; i < L; i++) scanf("%u", &b.v[i]);
     if (!strcmp(op, "mul")) fe29_mul(r, a, b);
+    else if (!strcmp(op, "sqr")) fe29_sqr(r, a);
+    else if (!strcmp(op, "mulacc")) {   // a b + c d with c = b reversed, d = a reversed (distinct operands from two vectors)
+        Fe29<P> c, d;
+        for (int i = 0; i < L; i++) c.v[i] = b.v[i] >> 1, d.v[i] = a.v[i] >> 1;
+        fe29_mulacc(r, a, b, c, d);
+    }
     else if (!strcmp(op, "sub4k1")) fe29_sub(r, a, b, F29<P>::BIAS4K1);
     else if (!strcmp(op, "sub16k2")) fe29_sub(r, a, b, F29<P>::BIAS16K2);
     else if (!strcmp(op, "sub3")) fe29_sub3(r, a, b, b);

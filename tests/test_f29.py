@@ -240,3 +240,42 @@ def test_f29_fq2_mul_sqr_extremes(field):
     res = run(lines)
     for r, e in zip(res, exp):
         assert bool(r[0]) == e
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_f29_sqr_and_mulacc(field):
+    """the dedicated square (doubled operand, symmetric half of the products) and the two-product multiply with one
+    reduction, at the widest operands their call sites produce"""
+    shape(field)
+    p = pyref.FIELDS[field][0]
+    Rp = 1 << (W * L)
+    top = p >> (W * (L - 1))
+    rng = random.Random(31)
+    nplus = MASK + (1 << (32 - W)) - 1
+    wide = MASK + 1 + 2 * (MASK + 1) + nplus
+    cases = []
+    for k in range(120):
+        if k == 0:
+            a = [2 * nplus] * (L - 1) + [16 * top]           # u = 2y in dbl: the widest operand a square sees
+        elif k == 1:
+            a = [nplus] * (L - 1) + [18 * top]
+        else:
+            a = spread_random(rng, rng.randrange(16 * p), 2 * nplus)
+        cases.append(a)
+    res = run([(field, "sqr", a, [0] * L) for a in cases])
+    for a, r in zip(cases, res):
+        assert all(x <= MASK for x in r[:L - 1])
+        assert val(r) * Rp % p == val(a) * val(a) % p and val(r) < val(a) * val(a) // Rp + p + 1
+    cases = []
+    for k in range(120):
+        if k == 0:
+            a, b = [nplus] * (L - 1) + [18 * top], [wide] * (L - 1) + [17 * top]     # r and t = q - x3 + 16p
+        else:
+            a, b = spread_random(rng, rng.randrange(18 * p), nplus), spread_random(rng, rng.randrange(17 * p), wide)
+        cases.append((a, b))
+    res = run([(field, "mulacc", a, b) for a, b in cases])
+    for (a, b), r in zip(cases, res):
+        c, d = [x >> 1 for x in b], [x >> 1 for x in a]
+        tot = val(a) * val(b) + val(c) * val(d)
+        assert all(x <= MASK for x in r[:L - 1])
+        assert val(r) * Rp % p == tot % p and val(r) < tot // Rp + p + 1

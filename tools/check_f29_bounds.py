@@ -38,6 +38,15 @@ def mul(a, b, name="mul"):
     return r
 
 
+def mulacc(a, b, c, d, name="mulacc"):
+    """(a b + c d) / R' with one reduction: both products in the same columns"""
+    col = L * (a.lb * b.lb + c.lb * d.lb) + L * (1 << (2 * W)) + (1 << (64 - W + 1))
+    assert col < 1 << 64, ("column overflow", name, a, b, c, d)
+    r = V(STRICT, (a.vb * b.vb + c.vb * d.vb) * P_OVER_R + 1.0, name)
+    assert r.vb < 20, ("value too large", name, r)
+    return r
+
+
 def add(a, b, name="add"):
     r = V(a.lb + b.lb, a.vb + b.vb, name)
     assert r.lb < 1 << 32
@@ -98,8 +107,7 @@ def check_shape(w, l, log2p_max, log2p_min):
     rr = mul(r, r)
     x3 = norm(sub(rr, [ppp, qq, qq], "8K3"))
     t = sub(qq, [x3], "16K2")
-    m1, m2 = mul(r, t), mul(Y1, ppp)
-    y3 = norm(sub(m1, [m2], "4K1"))
+    y3 = mulacc(r, t, norm(sub(V(0, 0), [Y1], "16K2")), ppp)
     stored(x3, y3, mul(ZZ1, pp), mul(ZZZ1, ppp))
     print("madd ok:", x3, y3)
 
@@ -115,8 +123,7 @@ def check_shape(w, l, log2p_max, log2p_min):
     rr = mul(r, r)
     x3 = norm(sub(rr, [ppp, qq, qq], "8K3"))
     t = sub(qq, [x3], "16K2")
-    m1, m2 = mul(r, t), mul(s1, ppp)
-    y3 = norm(sub(m1, [m2], "4K1"))
+    y3 = mulacc(r, t, norm(sub(V(0, 0), [s1], "4K1")), ppp)
     stored(x3, y3, mul(mul(ZZ1, ZZ2), pp), mul(mul(ZZZ1, ZZZ2), ppp))
     print("add ok: ", x3, y3)
 
@@ -130,8 +137,7 @@ def check_shape(w, l, log2p_max, log2p_min):
         m = norm(add(add(t, t), t))
         x3 = norm(sub(mul(m, m), [s, s], "4K2"))
         t = sub(s, [x3], "16K2")
-        m1, m2 = mul(m, t), mul(w, y)
-        y3 = norm(sub(m1, [m2], "4K1"))
+        y3 = mulacc(m, t, norm(sub(V(0, 0), [w], "4K1")), y)
         stored(x3, y3, mul(v, zz) if zz else v, mul(w, zzz) if zzz else w)
         print("%s ok: " % tag, x3, y3)
 
@@ -143,14 +149,6 @@ def check_shape(w, l, log2p_max, log2p_min):
 # ---------------------------------------------------------------------------------------------------------------
 # Fq2 (G2 twists): values are pairs; the operations mirror Fe29x2 in zk_field29.h and the C29x2 formulas of zk_curve29.h
 # ---------------------------------------------------------------------------------------------------------------
-def mulacc(a, b, c, d, name="mulacc"):
-    col = L * (a.lb * b.lb + c.lb * d.lb) + L * (1 << (2 * W)) + (1 << (64 - W + 1))
-    assert col < 1 << 64, ("column overflow", name, a, b, c, d)
-    r = V(STRICT, (a.vb * b.vb + c.vb * d.vb) * P_OVER_R + 1.0, name)
-    assert r.vb < 20, ("value too large", name, r)
-    return r
-
-
 def sub2(a, subs, bias, name="sub2"):
     return tuple(sub(a[i], [x[i] for x in subs], bias, name) for i in (0, 1))
 
