@@ -31,6 +31,7 @@ EXPORTS = [
     "zk_bases_free", "zk_msm", "zk_msm_device", "zk_msm_last_profile", "zk_ntt", "zk_ntt_device", "zk_coset_mul",
     "zk_coset_mul_device", "zk_ntt_coset_device", "zk_field_root_of_unity", "zk_field_multiplicative_generator", "zk_field_inverse",
     "zk_point_add", "zk_point_to_affine", "zk_fixed_base_mul_device", "zk_vec_op_device", "zk_groth16_witness_map_device",
+    "zk_fixed_base_msm_device",
 ]
 
 
@@ -83,6 +84,7 @@ def load(path=None):
     lib.zk_point_add.argtypes = [i32, vp, vp, vp]
     lib.zk_point_to_affine.argtypes = [i32, vp, vp]
     lib.zk_fixed_base_mul_device.argtypes = [i32, vp, u64, vp, vp]
+    lib.zk_fixed_base_msm_device.argtypes = [i32, vp, vp, u64, i32, vp, vp]
     lib.zk_vec_op_device.argtypes = [i32, i32, vp, vp, vp, u64, vp, vp]
     lib.zk_groth16_witness_map_device.argtypes = [i32, vp, vp, vp, ctypes.c_uint32, vp]
     lib.zk_msm_window_bits.argtypes = [i32, u64, i32]
@@ -313,6 +315,13 @@ def groth16_witness_map(field, a, b, c, stream=0):
 def fixed_base_mul_device(curve, d_scalars, d_out, n, stream=0):
     _check(load().zk_fixed_base_mul_device(curve_id(curve), _ptr(d_scalars), n, _ptr(d_out), ctypes.c_void_p(stream)),
            "zk_fixed_base_mul_device")
+
+
+def fixed_base_msm_device(curve, d_scalars, d_out, n, base=None, montgomery=False, stream=0):
+    """d_out[i] = [k_i] base (affine); base: numpy uint64 (x, y) Montgomery limbs on the host, None = the generator."""
+    b = _np64(base) if base is not None else None
+    _check(load().zk_fixed_base_msm_device(curve_id(curve), _ptr(b) if b is not None else None, _ptr(d_scalars), n, int(montgomery),
+                                           _ptr(d_out), ctypes.c_void_p(stream)), "zk_fixed_base_msm_device")
 
 
 from . import ark, halo2  # noqa: E402,F401  (interface mirrors)

@@ -3,6 +3,8 @@
   VariableBaseMSM.multi_scalar_mul(bases, scalars)   ark-ec 0.3  src/msm/variable_base.rs
   Radix2EvaluationDomain(num_coeffs)                 ark-poly 0.3 src/domain/radix2/mod.rs
       .fft_in_place / .ifft_in_place / .coset_fft_in_place / .coset_ifft_in_place
+  FixedBaseMSM.multi_scalar_mul(...)                 ark-ec 0.3  src/msm/fixed_base.rs  (key generation,
+                                                     lib/src/zk/encryption.rs:169 via ark-groth16 0.3 generate_parameters)
 
 reached from lib/src/zk/verifiable_encryption.rs:92, lib/src/zk/encryption.rs:76,
 lib/src/zk/sample_entries.rs:86, lib/src/zk/property.rs:133 via ark-groth16 0.3 create_proof
@@ -11,7 +13,8 @@ and error behaviour; the arithmetic runs in the HIP library.
 """
 import numpy as np
 
-from . import (Bases, coset_mul, curve_id, field_id, field_inverse, msm, multiplicative_generator, ntt, root_of_unity)
+from . import (Bases, coset_mul, curve_id, field_id, field_inverse, fixed_base_msm_device, msm, multiplicative_generator, ntt,
+               root_of_unity)
 
 
 class VariableBaseMSM:
@@ -22,6 +25,24 @@ class VariableBaseMSM:
         Returns the projective (Jacobian) sum."""
         n = min(bases.n, int(scalars.shape[0]))
         return msm(bases, scalars[:n], montgomery=False)
+
+
+class FixedBaseMSM:
+    """ark-ec 0.3 FixedBaseMSM: `get_mul_window_size` / `get_window_table` / `multi_scalar_mul`, followed upstream by
+    `batch_normalization_into_affine`.  The window table is an implementation detail of the device path (8-bit windows,
+    rebuilt per call), so the three upstream steps collapse into one call that returns affine points."""
+
+    @staticmethod
+    def get_mul_window_size(num_scalars):
+        """upstream heuristic (3 below 32 scalars, else ceil(ln n)); informational here -- the device path uses 8"""
+        import math
+        return 3 if num_scalars < 32 else int(math.ceil(math.log(num_scalars)))
+
+    @staticmethod
+    def multi_scalar_mul(curve, base, d_scalars, d_out, montgomery=False, stream=0):
+        """d_out[i] = [d_scalars[i]] base as affine points (device buffers); base = (x, y) Montgomery limbs or None (generator)"""
+        fixed_base_msm_device(curve, d_scalars, d_out, int(d_scalars.shape[0]), base=base, montgomery=montgomery, stream=stream)
+        return d_out
 
 
 class Radix2EvaluationDomain:

@@ -89,7 +89,7 @@ API int zk_shutdown(void) {
     for (auto& kv : g.tw) hipFree(kv.second.dev);
     g.tw.clear();
     g.tw_bytes = 0;
-    for (DevBuf* b : {&g.ntt_tmp, &g.pow_tbl, &g.msm_counts, &g.msm_digits, &g.msm_blockcnt, &g.msm_stage_idx, &g.msm_stage_low, &g.msm_queue, &g.msm_seg_out, &g.msm_subacc, &g.msm_sorted, &g.msm_buckets, &g.msm_part_a, &g.msm_part_b,
+    for (DevBuf* b : {&g.ntt_tmp, &g.pow_tbl, &g.fb_table, &g.fb_tmp, &g.msm_counts, &g.msm_digits, &g.msm_blockcnt, &g.msm_stage_idx, &g.msm_stage_low, &g.msm_queue, &g.msm_seg_out, &g.msm_subacc, &g.msm_sorted, &g.msm_buckets, &g.msm_part_a, &g.msm_part_b,
                       &g.scratch_in, &g.scratch_out})
         ws_free(*b);
     if (g.have_events) {
@@ -371,6 +371,24 @@ API int zk_fixed_base_mul_device(zk_curve_t c, const void* d_scalars, uint64_t n
     if (n == 0) return ZK_OK;
     if (!d_scalars || !d_out || !aligned16(d_scalars) || !aligned16(d_out) || n >= (1ull << 31)) return ZK_ERR_INVALID_ARG;
     CURVE_SWITCH(c, return fixed_base_run<C>((const Fe<typename C::Fr>*)d_scalars, n, (Affine<C>*)d_out, (hipStream_t)stream));
+    return ZK_OK;
+}
+
+API int zk_fixed_base_msm_device(zk_curve_t c, const void* base_affine_mont, const void* d_scalars, uint64_t n, int scalars_are_montgomery,
+                                 void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    ZK_TRY(require_init());
+    if (n == 0) return ZK_OK;
+    if (!d_scalars || !d_out || !aligned16(d_scalars) || !aligned16(d_out) || n >= (1ull << 31)) return ZK_ERR_INVALID_ARG;
+    CURVE_SWITCH(c, {
+        Affine<C> base;
+        if (base_affine_mont)
+            memcpy(&base, base_affine_mont, 2 * 4 * coord_words<C>());
+        else
+            curve_generator(base);
+        return fixed_base_msm_run<C>(base, (const Fe<typename C::Fr>*)d_scalars, n, scalars_are_montgomery ? 1 : 0, (Affine<C>*)d_out,
+                                     (hipStream_t)stream);
+    });
     return ZK_OK;
 }
 

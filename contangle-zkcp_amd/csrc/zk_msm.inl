@@ -283,4 +283,19 @@ int fixed_base_run(const Fe<typename C::Fr>* d_scalars, uint64_t n, Affine<C>* d
     HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
+// ark-ec 0.3 FixedBaseMSM (window table + multi_scalar_mul) + batch_normalization_into_affine for one base
+template <class C>
+int fixed_base_msm_run(const Affine<C>& base, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, Affine<C>* d_out, hipStream_t st) {
+    const uint32_t entries = (uint32_t)fb_windows<C>() * FB_ROW;
+    ZK_TRY(ws_get(g.fb_table, (size_t)entries * sizeof(Affine<C>)));
+    ZK_TRY(ws_get(g.fb_tmp, (size_t)n * sizeof(XYZZ<C>)));
+    Affine<C>* table = (Affine<C>*)g.fb_table.p;
+    XYZZ<C>* tmp = (XYZZ<C>*)g.fb_tmp.p;
+    ZK_LAUNCH((fixed_base_table_kernel<C>), (entries + 63) / 64, 64, 0, st, base, table, entries);
+    ZK_LAUNCH((fixed_base_msm_kernel<C>), (unsigned)((n + 63) / 64), 64, 0, st, (const Affine<C>*)table, d_scalars, tmp, (uint32_t)n, mont);
+    const uint64_t lanes = (n + FB_K - 1) / FB_K;
+    ZK_LAUNCH((xyzz_batch_to_affine_kernel<C>), (unsigned)((lanes + 63) / 64), 64, 0, st, (const XYZZ<C>*)tmp, d_out, (uint32_t)n);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
 }  // namespace zk

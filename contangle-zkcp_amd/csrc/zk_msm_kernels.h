@@ -667,4 +667,96 @@ __global__ void __launch_bounds__(64) fixed_base_mul_kernel(const Fe<typename C:
     out[i] = r;
 }
 
+// ------------------------------------------------------------------------------------------
+// Fixed-base windowed scalar multiplication: out[i] = [k_i] B for ONE base B -- ark-ec 0.3 `FixedBaseMSM::get_window_table`
+// + `FixedBaseMSM::multi_scalar_mul` + `ProjectiveCurve::batch_normalization_into_affine`, the shape of Groth16 key
+// generation (ark-groth16 0.3 generate_parameters: every query vector of the proving key is [s_i] g for one random
+// generator g; reached from the reference at lib/src/zk/encryption.rs:169).
+//   table[w * 255 + d - 1] = [d * 2^(8w)] B   (affine, FB_C = 8-bit unsigned windows: 32 x 255 points, 0.5 MB, L2-resident)
+//   fixed_base_msm_kernel   one lane per scalar: <= 32 mixed additions of table entries, no doublings
+//   xyzz_batch_to_affine_kernel   K = 8 points per lane share one field inversion (Montgomery's trick)
+// ------------------------------------------------------------------------------------------
+constexpr int FB_C = 8;
+constexpr uint32_t FB_ROW = (1u << FB_C) - 1;   // table entries per window
+constexpr int FB_K = 8;                         // points per inversion in the normalisation kernel
+
+template <class C>
+constexpr int fb_windows() {
+    return (C::Fr::BITS + FB_C - 1) / FB_C;
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) fixed_base_table_kernel(Affine<C> base, Affine<C>* __restrict__ table, uint32_t entries) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= entries) return;
+    const uint32_t w = t / FB_ROW, d = t % FB_ROW + 1;
+    XYZZ<C> acc;
+    xyzz_set_inf(acc);
+    for (int bit = FB_C - 1; bit >= 0; bit--) {   // [d] B
+        xyzz_dbl(acc);
+        if ((d >> bit) & 1) xyzz_add_mixed(acc, base);
+    }
+    for (uint32_t k = 0; k < w * FB_C; k++) xyzz_dbl(acc);   // ... * 2^(8w)
+    Affine<C> r;
+    xyzz_to_affine(r, acc);
+    table[t] = r;
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) fixed_base_msm_kernel(const Affine<C>* __restrict__ table, const Fe<typename C::Fr>* __restrict__ scalars,
+                                                            XYZZ<C>* __restrict__ out, uint32_t n, int mont) {
+    using Fr = typename C::Fr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<Fr> k = scalars[i];
+    if (mont) fe_from_mont(k, k);
+    XYZZ<C> acc;
+    xyzz_set_inf(acc);
+    for (int w = 0; w < fb_windows<C>(); w++) {
+        const uint32_t d = bits_at<Fr::N>(k.v, w * FB_C, FB_C);
+        if (d != 0) {
+            Affine<C> p = table[(uint32_t)w * FB_ROW + d - 1];
+            xyzz_add_mixed(acc, p);
+        }
+    }
+    out[i] = acc;
+}
+
+// out[i] = affine(in[i]); identity -> (0, 0).  Lane t owns points [FB_K t, FB_K (t + 1)): prefix products of their ZZZ,
+// one inversion, back-substitution.  1/ZZ = ZZ^2 / ZZZ^2 (ZZ^3 = ZZZ^2 is the XYZZ invariant).
+template <class C>
+__global__ void __launch_bounds__(64) xyzz_batch_to_affine_kernel(const XYZZ<C>* __restrict__ in, Affine<C>* __restrict__ out, uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lo = t * FB_K;
+    if (lo >= n) return;
+    const uint32_t cnt = n - lo < (uint32_t)FB_K ? n - lo : (uint32_t)FB_K;
+    Coord<C> pre[FB_K], run, z;
+    fe_one(run);
+    for (uint32_t k = 0; k < cnt; k++) {
+        pre[k] = run;                                  // product of the ZZZ before point k
+        z = in[lo + k].zzz;
+        if (fe_is_zero(in[lo + k].zz)) fe_one(z);      // the identity contributes a factor 1
+        fe_mul(run, run, z);
+    }
+    Coord<C> inv;
+    fe_inv(inv, run);
+    for (int k = (int)cnt - 1; k >= 0; k--) {
+        const XYZZ<C> p = in[lo + k];
+        Affine<C> r;
+        if (xyzz_is_inf(p)) {
+            fe_zero(r.x);
+            fe_zero(r.y);
+        } else {
+            Coord<C> izzz, t2, izz;
+            fe_mul(izzz, inv, pre[k]);                 // 1 / ZZZ_k
+            fe_mul(inv, inv, p.zzz);                   // drop ZZZ_k from the running inverse
+            fe_mul(t2, izzz, p.zz);                    // ZZ / ZZZ = 1 / z
+            fe_sqr(izz, t2);                           // 1 / ZZ
+            fe_mul(r.x, p.x, izz);
+            fe_mul(r.y, p.y, izzz);
+        }
+        out[lo + k] = r;
+    }
+}
+
 }  // namespace zk

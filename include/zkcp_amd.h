@@ -156,6 +156,15 @@ int zk_point_to_affine(zk_curve_t c, const void *jac, void *affine_out);        
 int zk_fixed_base_mul_device(zk_curve_t c, const void *scalars_canonical_dev, uint64_t n, void *affine_out_dev,
                              void *hip_stream);
 
+/* out[i] = [k_i] B (affine, Montgomery; identity -> (0, 0)) for ONE base B: replaces, for Groth16 key generation
+ * (ark-groth16 0.3 generate_parameters, reached from the reference at lib/src/zk/encryption.rs:169), the upstream sequence
+ *   ark_ec::msm::FixedBaseMSM::get_window_table + FixedBaseMSM::multi_scalar_mul   (ark-ec 0.3 src/msm/fixed_base.rs)
+ *   ProjectiveCurve::batch_normalization_into_affine                                  (ark-ec 0.3 src/lib.rs)
+ * base_affine_mont: host pointer to (x, y) in Montgomery form, or NULL for the curve's generator.  Scalars and output are
+ * device buffers; the window table (8-bit windows) is built on the device per call. */
+int zk_fixed_base_msm_device(zk_curve_t c, const void *base_affine_mont, const void *scalars_dev, uint64_t n,
+                             int scalars_are_montgomery, void *affine_out_dev, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

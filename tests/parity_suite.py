@@ -318,6 +318,31 @@ def check_msm_sort_shapes(zk, cname, n, window_bits_list):
         assert (affine_of(zk, cname, zk.point_add(cname, lo, hi)) == exp).all(), (cname, window_bits, "sharded")
     bases.free()
 
+def check_fixed_base_msm(zk, cname, n, seed=91):
+    """zk_fixed_base_msm_device (8-bit window table + batched normalisation; ark-ec FixedBaseMSM + batch_normalization)
+    against the oracle's plain double-and-add: generator and an arbitrary base, canonical and Montgomery scalars,
+    edge scalars 0 / 1 / r-1 / 2^k, a length that is not a multiple of the normalisation batch"""
+    sf = pyref.CURVES[cname][1]
+    r = pyref.FIELDS[sf][0]
+    ks = scalars_for(cname, n, seed)
+    edge = [0, 1, r - 1, 1 << 8, (1 << 8) - 1, 1 << 248, 255 << 16]
+    ks[:len(edge)] = orc.ints_to_array(edge, 4)
+    nl = zk.base_limbs(cname)
+    exp = orc.fixed_base_mul(cname, ks, threads=8)
+    out = to_device(zk, np.zeros((n, 2 * nl), dtype=np.uint64))
+    zk.ark.FixedBaseMSM.multi_scalar_mul(cname, None, to_device(zk, ks), out)
+    got = to_host(zk, out)
+    assert (got == exp).all(), (cname, "generator")
+    assert (got[0] == 0).all()                                   # [0] G = identity = (0, 0)
+    # an arbitrary base B = [7919] G, Montgomery-form scalars (what a Rust caller holding Fr values would pass)
+    seven = orc.fixed_base_mul(cname, orc.ints_to_array([7919], 4))[0]
+    m = min(n, 96)
+    exp_b = np.stack([orc.scalar_mul(cname, seven, ks[i]) for i in range(m)])
+    out = to_device(zk, np.zeros((m, 2 * nl), dtype=np.uint64))
+    zk.ark.FixedBaseMSM.multi_scalar_mul(cname, seven, to_device(zk, orc.to_mont(sf, ks[:m])), out, montgomery=True)
+    assert (to_host(zk, out) == exp_b).all(), (cname, "base 7919 G")
+
+
 def check_ntt_fused_coset(zk, name, logn, threads=8):
     """zk_ntt_coset_device: the coset shifts fused into the first / last NTT pass (on-the-fly powers from two small
     tables) against the oracle's ark-poly coset_fft / coset_ifft restatement."""

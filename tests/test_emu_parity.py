@@ -79,6 +79,11 @@ def test_vec_ops_and_witness_map(zk):
     ps.check_witness_map(zk, "Bn254Fr", 4)
 
 
+def test_fixed_base_msm(zk):
+    ps.check_fixed_base_msm(zk, "Vesta", 21)
+    ps.check_fixed_base_msm(zk, "Bn254G2", 13)
+
+
 def test_msm_sort_shapes(zk):
     ps.check_msm_sort_shapes(zk, "Vesta", 2100, (5, 13))        # 3 scalar blocks; 1 and 2 ranges per window
     ps.check_msm_sort_shapes(zk, "Bls381G1", 90, (7,))

@@ -144,6 +144,23 @@ def test_fixed_base_mul(zk, cname):
     assert (got == orc.fixed_base_mul(cname, ks, threads=8)).all()
 
 
+@pytest.mark.parametrize("cname", ps.CURVES)
+def test_fixed_base_msm(zk, cname):
+    ps.check_fixed_base_msm(zk, cname, 1003)
+
+
+def test_fixed_base_msm_matches_plain_kernel_2p16(zk):
+    """windowed fixed-base path vs the plain double-and-add kernel at 2^16 (bit-exact affine output)"""
+    import torch
+    n = 1 << 16
+    ks, d_plain = _device_bases(zk, "Bls381G1", n, seed=5)
+    d_k = torch.from_numpy(ks.view(np.int64)).cuda()
+    d_win = torch.empty_like(d_plain)
+    zk.fixed_base_msm_device("Bls381G1", d_k, d_win, n)
+    torch.cuda.synchronize()
+    assert torch.equal(d_win, d_plain)
+
+
 @pytest.mark.parametrize("cname", ["Pallas", "Vesta"])
 def test_msm_full_size_2p20(zk, cname):
     """BASELINE configs[1]: 2^20-point MSM.  Bit-exact vs the oracle's ark restatement (threads = host cores),
