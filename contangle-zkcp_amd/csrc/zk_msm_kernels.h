@@ -528,7 +528,9 @@ __global__ void __launch_bounds__(256) msm_combine_big_kernel(const MsmQueue* __
 // has just swept L2 (measured: tools/shard_model.py with ZK_MSM_SPLIT).  It is therefore a little state machine with ONE
 // addition site and ONE doubling site (xyzz_add_nodbl + xyzz_dbl, ~40 KB) and wave-uniform operand selection:
 //   steps 0 .. 2L-1        run += B_l ; wsum += run          (l = L-1 .. 0, the next bucket prefetched under the additions)
-//   then 2 per bit of tL   acc = 2 acc ; acc += run if the bit is set   (MSB first, bit count uniform over the grid)
+//   then                   t2 = 2 run ; t3 = t2 + run
+//   3 per two bits of t    acc = 4 acc (two steps) ; acc += run / t2 / t3 by the digit   (MSB first, uniform digit count)
+//   log2 L                 acc = 2 acc
 //   last                   wsum += acc
 template <class C>
 __global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restrict__ buckets, XYZZ<C>* __restrict__ out, uint32_t nbk, uint32_t L,
@@ -544,16 +546,28 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restric
     const XYZZ<C>* src = buckets + (uint64_t)w * nbk + (uint64_t)t * L;
     const uint32_t avail = nbk - t * L < L ? nbk - t * L : L;   // the last slice of a window may be short
     if (avail > 0) b = src[avail - 1];
-    const uint32_t m = t * L;
-    const uint32_t mmax = (slices_per_window - 1) * L;
-    const uint32_t nbits = mmax ? 32u - (uint32_t)__clz(mmax) : 0u;
-    const uint32_t nsteps = 2 * L + 2 * nbits + 1;
+    // multiplier phase: wsum += [t * L] run.  2-bit windows over t (run, 2 run, 3 run precomputed: 3 steps per two bits
+    // instead of 4), then log2(L) doublings (L is a power of two whenever it is > 1).  Step counts are uniform over the grid.
+    const uint32_t tmax = slices_per_window - 1;
+    const uint32_t tbits = tmax ? 32u - (uint32_t)__clz(tmax) : 0u;
+    const uint32_t ndig = (tbits + 1) / 2;
+    const uint32_t log_l = 31u - (uint32_t)__clz(L);
+    const bool pow2 = (L & (L - 1)) == 0;
+    const uint32_t mult = pow2 ? t : t * L;                       // multiplier scanned by the digit loop
+    const uint32_t mbits = pow2 ? tbits : (tmax ? 32u - (uint32_t)__clz(tmax * L) : 0u);
+    const uint32_t mdig = pow2 ? ndig : (mbits + 1) / 2;
+    const uint32_t tail = pow2 ? log_l : 0u;
+    const uint32_t s_mul = 2 * L;                                 // first step of the multiplier phase
+    const uint32_t nsteps = mdig ? s_mul + 2 + 3 * mdig + tail + 1 : s_mul;
+    XYZZ<C> t2, t3;
+    xyzz_set_inf(t2);
+    xyzz_set_inf(t3);
 #pragma unroll 1
     for (uint32_t s = 0; s < nsteps; s++) {
         XYZZ<C> X, Y;
         bool dbl = false, on = true;
-        int kind;
-        if (s < 2 * L) {
+        int kind;   // destination: 0 run, 1 wsum, 2 acc, 3 t2, 4 t3
+        if (s < s_mul) {
             const uint32_t l = L - 1 - (s >> 1);
             if ((s & 1) == 0) {
                 kind = 0;
@@ -566,15 +580,32 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restric
                 X = wsum;
                 Y = run;
             }
-        } else if (s < 2 * L + 2 * nbits) {
-            const uint32_t j = s - 2 * L, bit = nbits - 1 - (j >> 1);
-            X = acc;
+        } else if (s == s_mul) {             // t2 = 2 run
+            kind = 3;
+            X = run;
             Y = run;
+            dbl = true;
+        } else if (s == s_mul + 1) {         // t3 = t2 + run
+            kind = 4;
+            X = t2;
+            Y = run;
+        } else if (s < s_mul + 2 + 3 * mdig) {
+            const uint32_t j = s - s_mul - 2, dg = mdig - 1 - j / 3, ph = j % 3;
             kind = 2;
-            if ((j & 1) == 0)
+            X = acc;
+            if (ph < 2) {
+                Y = acc;
                 dbl = true;
-            else
-                on = (m >> bit) & 1;
+            } else {
+                const uint32_t v = (mult >> (2 * dg)) & 3u;
+                on = v != 0;
+                Y = v == 1 ? run : (v == 2 ? t2 : t3);
+            }
+        } else if (s < nsteps - 1) {         // acc = L * acc
+            kind = 2;
+            X = acc;
+            Y = acc;
+            dbl = true;
         } else {
             kind = 1;
             X = wsum;
@@ -587,8 +618,12 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restric
             run = X;
         else if (kind == 1)
             wsum = X;
-        else
+        else if (kind == 2)
             acc = X;
+        else if (kind == 3)
+            t2 = X;
+        else
+            t3 = X;
     }
     out[gt] = wsum;
 }

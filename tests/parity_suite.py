@@ -318,6 +318,23 @@ def check_msm_sort_shapes(zk, cname, n, window_bits_list):
         assert (affine_of(zk, cname, zk.point_add(cname, lo, hi)) == exp).all(), (cname, window_bits, "sharded")
     bases.free()
 
+def check_msm_slice_lengths(zk, cname, n, window_bits):
+    """the bucket reduction for several slice lengths L (X_t = W_t + [t L] S_t with the 2-bit windowed multiplier):
+    powers of two (the digits of t, then log2 L doublings), a non-power of two (digits of t L), L = all buckets"""
+    pts = bases_for(cname, n)
+    sc = scalars_for(cname, n, 23)
+    exp = orc.msm_ark(cname, pts, sc, threads=8)
+    bases = zk.Bases(cname, pts)
+    try:
+        for L in (1, 2, 3, 8, 64, 1024):
+            os.environ["ZK_MSM_SLICE"] = str(L)
+            got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
+            assert (got == exp).all(), (cname, L)
+    finally:
+        os.environ.pop("ZK_MSM_SLICE", None)
+    bases.free()
+
+
 def check_fixed_base_msm(zk, cname, n, seed=91):
     """zk_fixed_base_msm_device (8-bit window table + batched normalisation; ark-ec FixedBaseMSM + batch_normalization)
     against the oracle's plain double-and-add: generator and an arbitrary base, canonical and Montgomery scalars,

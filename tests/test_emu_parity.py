@@ -79,6 +79,11 @@ def test_vec_ops_and_witness_map(zk):
     ps.check_witness_map(zk, "Bn254Fr", 4)
 
 
+def test_msm_slice_lengths(zk):
+    ps.check_msm_slice_lengths(zk, "Vesta", 300, 8)
+    ps.check_msm_slice_lengths(zk, "Bn254G2", 60, 6)
+
+
 def test_fixed_base_msm(zk):
     ps.check_fixed_base_msm(zk, "Vesta", 21)
     ps.check_fixed_base_msm(zk, "Bn254G2", 13)

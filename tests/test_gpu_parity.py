@@ -144,6 +144,11 @@ def test_fixed_base_mul(zk, cname):
     assert (got == orc.fixed_base_mul(cname, ks, threads=8)).all()
 
 
+@pytest.mark.parametrize("cname", ["Vesta", "Bls381G1", "Bls381G2"])
+def test_msm_slice_lengths(zk, cname):
+    ps.check_msm_slice_lengths(zk, cname, 1 << 13, 12)
+
+
 @pytest.mark.parametrize("cname", ps.CURVES)
 def test_fixed_base_msm(zk, cname):
     ps.check_fixed_base_msm(zk, cname, 1003)

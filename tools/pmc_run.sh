@@ -3,7 +3,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-prof}
-ARGS="${2:---steps 3 --warmup 1 --no-cpu-baseline}"
+ARGS="${2:---steps 3 --warmup 1 --no-cpu-baseline --serial}"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1 || echo "stats pass failed"
