@@ -87,6 +87,7 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         const uint32_t nreg = (uint32_t)nw_all * sh.nranges;                  // (window, bucket range) regions
         const uint32_t nblocks = (uint32_t)((n + MSM_SBLK - 1) / MSM_SBLK);    // scalar blocks of the count / stage kernels
         if (nreg > 4096 || sh.nranges > 64) return ZK_ERR_UNSUPPORTED;         // LDS tables of those kernels (c <= 16: <= 1024, 64)
+        if ((uint64_t)n * (uint64_t)nw_all >= (1ull << 32)) return ZK_ERR_UNSUPPORTED;   // entry positions are u32 (2^27 points x 16 windows fit)
         // counts | offs | order | wg_total | region_base
         ZK_TRY(ws_get(g.msm_counts, ((size_t)nbuckets * 3 + 2 * (size_t)nreg) * 4));
         uint32_t* counts = (uint32_t*)g.msm_counts.p;
@@ -140,8 +141,8 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
             for (auto& e : g.ev) HIP_TRY(hipEventCreate(&e));
             g.have_events = true;
         }
-        // resident waves per SIMD: the F29 kernel holds 138 VGPRs (3 fit), the 32-bit one 119 (4 fit); tools/tune_msm.py
-        unsigned waves_per_simd = CK::EXT == 29 ? 3 : (CK::EXT == 58 ? 2 : 4);
+        // resident waves per SIMD = what the kernel was compiled for (msm_acc_waves); ZK_MSM_WAVES launches fewer
+        unsigned waves_per_simd = (unsigned)msm_acc_waves<CK>();
         if (const char* e = getenv("ZK_MSM_WAVES")) {
             int v = atoi(e);
             if (v >= 1 && v <= 8) waves_per_simd = (unsigned)v;

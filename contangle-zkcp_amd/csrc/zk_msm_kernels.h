@@ -344,13 +344,24 @@ __device__ __forceinline__ void accumulate_slice(XYZZ<C>& acc, const Affine<C>* 
 // wave's batch (LDS cursor), and the wave refills its batch from the global queue 64 buckets at a time.  Buckets
 // are visited largest size class first (rank-major over the per-range size-sorted lists), so the queue drains
 // into the shortest buckets and all SIMDs finish together; lanes never wait for a longer neighbour.
+#ifndef ZK_ACC_WAVES_9
+#define ZK_ACC_WAVES_9 4
+#endif
 constexpr uint32_t MSM_BATCH = 64;
 // Visiting order: rank-major over the per-range size-sorted bucket lists, MSM_RANKW buckets of a range at a time.  The
 // narrower the rank, the closer the order is to globally largest-first (512-bucket ranges: 32 ranks).
 constexpr uint32_t MSM_RANKW = 16;
 
+// resident waves per SIMD the accumulate kernel is compiled for: the 9-limb lazy form needs 134 VGPRs unconstrained (3 waves);
+// held to 128 (8 dwords of scratch) a fourth wave fits -- issue efficiency grows with the number of resident waves
 template <class C>
-__global__ void __launch_bounds__(64) msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+constexpr int msm_acc_waves() {
+    if constexpr (C::EXT == 29) return F29<typename C::Fq>::L <= 9 ? ZK_ACC_WAVES_9 : 2;
+    if constexpr (C::EXT == 58) return F29<typename C::Fq>::L <= 9 ? 2 : 1;
+    return 4;
+}
+template <class C>
+__global__ void __launch_bounds__(64, msm_acc_waves<C>()) msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                       const uint32_t* __restrict__ offs, const uint32_t* __restrict__ counts,
                                       const uint32_t* __restrict__ order, XYZZ<C>* __restrict__ buckets, MsmShape sh,
                                       MsmQueue* __restrict__ q, MsmSeg* __restrict__ seg_list, uint32_t* __restrict__ big_list) {

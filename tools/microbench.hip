@@ -58,6 +58,36 @@ __global__ void k_fma64(double* out, double a, double b) {
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
 }
+// the 64-bit VALU helpers the lazy-limb product leans on besides the MAD (exact instructions, 8 independent chains)
+#define ASM8(INSN)                                                                                                   \
+    for (int i = 0; i < ITERS; i++) {                                                                                \
+        asm volatile(INSN : "+v"(x0) : "v"(y)); asm volatile(INSN : "+v"(x1) : "v"(y)); asm volatile(INSN : "+v"(x2) : "v"(y)); \
+        asm volatile(INSN : "+v"(x3) : "v"(y)); asm volatile(INSN : "+v"(x4) : "v"(y)); asm volatile(INSN : "+v"(x5) : "v"(y)); \
+        asm volatile(INSN : "+v"(x6) : "v"(y)); asm volatile(INSN : "+v"(x7) : "v"(y));                              \
+    }
+__global__ void k_lshladd64(uint32_t* out, uint32_t a, uint32_t b) {
+    uint64_t x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7, y = ((uint64_t)a << 32) | b;
+    ASM8("v_lshl_add_u64 %0, %0, 0, %1")
+    uint64_t s = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+__global__ void k_lshr64(uint32_t* out, uint32_t a, uint32_t b) {
+    uint64_t x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7, y = ((uint64_t)a << 32) | b;
+    ASM8("v_lshrrev_b64 %0, 1, %1")
+    uint64_t s = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+__global__ void k_alignbit(uint32_t* out, uint32_t a, uint32_t b) {
+    uint32_t x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7, y = a ^ b;
+    ASM8("v_alignbit_b32 %0, %1, %0, 29")
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
+}
+__global__ void k_addco(uint32_t* out, uint32_t a, uint32_t b) {
+    uint32_t x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7, y = a ^ b;
+    ASM8("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %1, vcc")
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
+}
+
 template <class F, int CH>
 __global__ void k_femul(Fe<F>* out, const Fe<F>* in, int iters) {
     Fe<F> x[CH], y = in[threadIdx.x & 7];
@@ -153,6 +183,14 @@ int main() {
         printf("waves/CU=%2d  v_add+v_xor (2 ops): %5.2f Tops/s\n", wpb * 2, 2 * ops / t / 1e9);
         t = time_ms([&] { hipLaunchKernelGGL(k_fma64, dim3(blocks), dim3(wpb * 64), 0, 0, (double*)d, 1.0000001, 0.5); });
         printf("waves/CU=%2d  v_fma_f64     : %8.2f Tops/s\n", wpb * 2, ops / t / 1e9);
+        t = time_ms([&] { hipLaunchKernelGGL(k_lshladd64, dim3(blocks), dim3(wpb * 64), 0, 0, d, 0x9e3779b9u, 0x85ebca6bu); });
+        printf("waves/CU=%2d  v_lshl_add_u64: %8.2f Tops/s\n", wpb * 2, ops / t / 1e9);
+        t = time_ms([&] { hipLaunchKernelGGL(k_lshr64, dim3(blocks), dim3(wpb * 64), 0, 0, d, 0x9e3779b9u, 0x85ebca6bu); });
+        printf("waves/CU=%2d  v_lshrrev_b64 : %8.2f Tops/s\n", wpb * 2, ops / t / 1e9);
+        t = time_ms([&] { hipLaunchKernelGGL(k_alignbit, dim3(blocks), dim3(wpb * 64), 0, 0, d, 0x9e3779b9u, 0x85ebca6bu); });
+        printf("waves/CU=%2d  v_alignbit_b32: %8.2f Tops/s\n", wpb * 2, ops / t / 1e9);
+        t = time_ms([&] { hipLaunchKernelGGL(k_addco, dim3(blocks), dim3(wpb * 64), 0, 0, d, 0x9e3779b9u, 0x85ebca6bu); });
+        printf("waves/CU=%2d  v_add_co+v_addc_co (2 ops): %5.2f Tops/s\n", wpb * 2, 2 * ops / t / 1e9);
     }
     for (int wpb : {1, 2, 4}) {
         bench_field<PallasFp>("PallasFp", cus * 4, wpb);
