@@ -46,6 +46,15 @@ def test_ntt_two_pass_default_plan(zk):
     ps.check_ntt_vs_oracle(zk, "PallasFp", 12)
 
 
+@pytest.mark.parametrize("block,logt", [("64", "2"), ("64", "4"), ("128", "3")])
+def test_ntt_butterflies_per_lane(zk, monkeypatch, block, logt):
+    # 1, 2 and 8 butterflies per lane and stage
+    monkeypatch.setenv("ZK_NTT_BLOCK", block)
+    monkeypatch.setenv("ZK_NTT_LOGT", logt)
+    ps.check_ntt_vs_oracle(zk, "PallasFp", 12)
+    ps.check_ntt_vs_oracle(zk, "Bls381Fr", 11)
+
+
 def test_msm_golden(zk):
     ps.check_msm_golden(zk)
 
