@@ -101,10 +101,11 @@ def build_emu(force=False, verbose=False, sanitize=False, jobs=None):
     objdir = os.path.join(PKG, "build", "emu_ubsan" if sanitize else "emu")
     if force:
         shutil.rmtree(objdir, ignore_errors=True)
-    base = ["g++", "-O2", "-std=c++17", "-fPIC", "-DZK_EMU", "-fvisibility=hidden", "-I" + EMU_DIR,
+    # (the sanitized build is -O1 without debug info: at -O2 -g the largest unit alone compiles for six minutes)
+    base = ["g++", "-O1" if sanitize else "-O2", "-std=c++17", "-fPIC", "-DZK_EMU", "-fvisibility=hidden", "-I" + EMU_DIR,
             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if sanitize:
-        base += ["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-g"]
+        base += ["-fsanitize=undefined", "-fno-sanitize-recover=undefined"]
     objs = _compile_all(base, objdir, [os.path.join(EMU_DIR, "emu_hip.h")], verbose, jobs)
     link = ["g++", "-shared", "-fPIC"] + (["-fsanitize=undefined"] if sanitize else []) + \
            ["-I" + EMU_DIR, "-O2", "-std=c++17", os.path.join(EMU_DIR, "emu_hip.cpp")] + objs + ["-o", out + ".tmp"]
