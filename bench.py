@@ -288,7 +288,7 @@ def bench_groth16(args, zk, zkdist, ps, pyref, torch, dist, np, world, rank, st)
     def make_bases(curve, n, seed):
         ks = ps.scalars_for(curve, n, seed)
         d = torch.empty((n, 2 * zk.base_limbs(curve)), dtype=torch.int64, device="cuda")
-        zk.fixed_base_mul_device(curve, torch.from_numpy(ks.view(np.int64)).cuda(), d, n, stream=st)
+        zk.fixed_base_msm_device(curve, torch.from_numpy(ks.view(np.int64)).cuda(), d, n, stream=st)   # windowed fixed-base path
         torch.cuda.synchronize()
         return zk.Bases(curve, device_tensor=d, n=n)
 
