@@ -236,9 +236,8 @@ def bench_halo2(args, zk, zkdist, ps, torch, dist, np, curve, sfield, n, bases, 
             if c % world == rank:
                 d_work.copy_(d_a)
                 zk.ntt(sfield, d_work, omega_inv, scale_by_n_inv=True, stream=st)                         # lagrange_to_coeff
-                d_ext.zero_()
                 d_ext[:n].copy_(d_work)
-                zk.ntt(sfield, d_ext, omega_ext, stream=st, coset_pre=zeta)                               # coeff_to_extended (zeta shift fused)
+                zk.halo2.coeff_to_extended(sfield, d_ext, k, omega_ext, zeta, stream=st)                  # zero-extend + zeta shift + NTT, fused
         if rank == 0:
             zk.ntt(sfield, d_ext, omega_ext_inv, scale_by_n_inv=True, stream=st, coset_post=zeta_inv)     # extended_to_coeff (quotient)
 

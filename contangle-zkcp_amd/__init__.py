@@ -31,7 +31,7 @@ EXPORTS = [
     "zk_bases_free", "zk_msm", "zk_msm_device", "zk_msm_last_profile", "zk_ntt", "zk_ntt_device", "zk_coset_mul",
     "zk_coset_mul_device", "zk_ntt_coset_device", "zk_field_root_of_unity", "zk_field_multiplicative_generator", "zk_field_inverse",
     "zk_point_add", "zk_point_to_affine", "zk_fixed_base_mul_device", "zk_vec_op_device", "zk_groth16_witness_map_device",
-    "zk_fixed_base_msm_device",
+    "zk_fixed_base_msm_device", "zk_ntt_extend_device",
 ]
 
 
@@ -76,6 +76,7 @@ def load(path=None):
     lib.zk_ntt.argtypes = [i32, vp, ctypes.c_uint32, vp, i32]
     lib.zk_ntt_device.argtypes = [i32, vp, ctypes.c_uint32, vp, i32, vp]
     lib.zk_ntt_coset_device.argtypes = [i32, vp, ctypes.c_uint32, vp, i32, vp, vp, vp]
+    lib.zk_ntt_extend_device.argtypes = [i32, vp, ctypes.c_uint32, ctypes.c_uint32, vp, i32, vp, vp, vp]
     lib.zk_coset_mul.argtypes = [i32, vp, ctypes.c_uint32, vp]
     lib.zk_coset_mul_device.argtypes = [i32, vp, ctypes.c_uint32, vp, vp]
     lib.zk_field_root_of_unity.argtypes = [i32, ctypes.c_uint32, vp]
@@ -245,13 +246,14 @@ def msm_last_profile():
     return {k: getattr(p, k) for k, _ in MsmProfile._fields_}
 
 
-def ntt(field, a, omega, scale_by_n_inv=False, stream=0, coset_pre=None, coset_post=None, device=False):
+def ntt(field, a, omega, scale_by_n_inv=False, stream=0, coset_pre=None, coset_post=None, device=False, in_log=None):
     """In-place size-2^k DFT with root `omega` (Montgomery); numpy (host, returns a new array) or torch GPU tensor.
     coset_pre / coset_post: a[i] *= g^i before / a[k] *= g^k after the transform, fused into the first / last pass on
-    device buffers.  device=True treats a numpy array as a device buffer (only meaningful under the CPU test emulator)."""
+    device buffers.  device=True treats a numpy array as a device buffer (only meaningful under the CPU test emulator).
+    in_log: the input is a[:2^in_log] zero-extended to len(a) (halo2 coeff_to_extended); the padding is never read."""
     lib = load()
     om = _np64(omega)
-    if isinstance(a, np.ndarray) and not device:
+    if isinstance(a, np.ndarray) and not device and in_log is None:
         buf = _np64(a).copy()
         n = buf.shape[0]
         log_n = n.bit_length() - 1
@@ -265,6 +267,13 @@ def ntt(field, a, omega, scale_by_n_inv=False, stream=0, coset_pre=None, coset_p
     n = int(a.shape[0])
     log_n = n.bit_length() - 1
     assert n == 1 << log_n
+    if in_log is not None:      # zero-extended input (device buffers): only a[:2^in_log] is read
+        gp = _np64(coset_pre) if coset_pre is not None else None
+        gq = _np64(coset_post) if coset_post is not None else None
+        _check(lib.zk_ntt_extend_device(field_id(field), _ptr(a), log_n, int(in_log), _ptr(om), int(scale_by_n_inv),
+                                        _ptr(gp) if gp is not None else None, _ptr(gq) if gq is not None else None,
+                                        ctypes.c_void_p(stream)), "zk_ntt_extend_device")
+        return a
     if coset_pre is None and coset_post is None:
         _check(lib.zk_ntt_device(field_id(field), _ptr(a), log_n, _ptr(om), int(scale_by_n_inv), ctypes.c_void_p(stream)),
                "zk_ntt_device")

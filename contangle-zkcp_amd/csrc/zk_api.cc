@@ -257,6 +257,23 @@ API int zk_ntt_coset_device(zk_field_t f, void* a, uint32_t log_n, const void* o
     });
     return ZK_ERR_INVALID_ARG;
 }
+API int zk_ntt_extend_device(zk_field_t f, void* a, uint32_t log_n, uint32_t log_in, const void* omega, int scale, const void* g_pre,
+                             const void* g_post, void* stream) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    ZK_TRY(require_init());
+    if (!a || !omega || !aligned16(a) || log_in > log_n) return ZK_ERR_INVALID_ARG;
+    FIELD_SWITCH(f, {
+        Fe<F> w, gp, gq;
+        host_load(w, omega);
+        if (g_pre) host_load(gp, g_pre);
+        if (g_post) host_load(gq, g_post);
+        if (log_n > 0 && log_in == 0) {   // a single coefficient: in_log = 0 means "all" to the pass kernel, so pad explicitly
+            HIP_TRY(hipMemsetAsync((Fe<F>*)a + 1, 0, (((size_t)1 << log_n) - 1) * sizeof(Fe<F>), (hipStream_t)stream));
+        }
+        return ntt_run<F>((int)f, (Fe<F>*)a, log_n, w, scale, (hipStream_t)stream, g_pre ? &gp : nullptr, g_post ? &gq : nullptr, log_in);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
 API int zk_coset_mul_device(zk_field_t f, void* a, uint32_t log_n, const void* gm, void* stream) {
     std::lock_guard<std::mutex> lk(g.mu);
     ZK_TRY(require_init());

@@ -131,7 +131,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <class F>
 int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st, const Fe<F>* g_pre = nullptr,
-            const Fe<F>* g_post = nullptr);
+            const Fe<F>* g_post = nullptr, uint32_t in_log = 0);
 template <class F>
 int coset_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st);
 template <class F>

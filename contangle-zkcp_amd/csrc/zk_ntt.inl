@@ -153,7 +153,7 @@ int pow_tables(const Fe<F>& gshift, uint32_t logn, int field, hipStream_t st, Po
 // size-2^logn DFT of `a` with root omega; optionally fused with a[i] *= g_pre^i before and a[k] *= g_post^k after
 template <class F>
 int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st, const Fe<F>* g_pre,
-            const Fe<F>* g_post) {
+            const Fe<F>* g_post, uint32_t in_log) {
     if (logn == 0) return ZK_OK;  // size-1 transform is the identity, n^-1 = 1 and g^0 = 1
     PowTables<F> tpre{nullptr, nullptr}, tpost{nullptr, nullptr};
     if (g_pre) ZK_TRY(pow_tables<F>(*g_pre, logn, field, st, &tpre));
@@ -189,6 +189,7 @@ int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_fl
         A.nd = plan.nd;
         for (int i = 0; i < plan.nd; i++) A.rd[i] = plan.rd[i];
         A.pre = (p == 0 && g_pre) ? 1 : 0;
+        A.in_log = (p == 0 && in_log > 0 && in_log < logn) ? (int)in_log : 0;
         A.post = (A.last && g_post) ? 1 : 0;
         const Fe<F>* src;
         Fe<F>* dst;

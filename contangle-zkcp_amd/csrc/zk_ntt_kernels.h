@@ -132,6 +132,7 @@ struct NttPass {
     int rd[4];  // r_1..r_P
     int pre;    // first pass multiplies input element i by g_pre^i on load   (ark coset_fft = distribute_powers ; fft)
     int post;   // last pass multiplies output element k by g_post^k on store (ark coset_ifft = ifft ; distribute_powers)
+    int in_log; // first pass: only the first 2^in_log input elements are read, the rest count as zero (halo2 coeff_to_extended); 0 = all
 };
 
 template <class F>
@@ -200,8 +201,13 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(const Fe<F>* __restrict_
             j = e >> A.log_t;
         }
         const uint64_t gi = base + j * stride_j + t * stride_t;
-        Fe<F> x = in[gi];
-        if (A.pre) mul_pow(x, pre, gi);
+        Fe<F> x;
+        if (A.in_log > 0 && (gi >> A.in_log) != 0) {
+            fe_zero(x);   // zero padding is implied, never stored or read
+        } else {
+            x = in[gi];
+            if (A.pre) mul_pow(x, pre, gi);
+        }
         const uint32_t p = pos(j, t);
         ZK_UNROLL
         for (int l = 0; l < NL; l++) lds[l * RT + p] = x.v[l];

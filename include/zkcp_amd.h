@@ -129,6 +129,12 @@ int zk_ntt_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *om
 int zk_ntt_coset_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *omega_mont_host, int scale_by_n_inv,
                         const void *g_pre_mont_host, const void *g_post_mont_host, void *hip_stream);
 
+/* The same transform on a zero-extended input: only a[0 .. 2^log_in) is read, a[2^log_in .. 2^log_n) counts as zero and is
+ * overwritten with the result -- halo2 0.2 EvaluationDomain::coeff_to_extended (`a.resize(extended_len(), 0)` ; zeta
+ * shift ; best_fft on the extended domain), without storing or re-reading the padding.  log_in <= log_n. */
+int zk_ntt_extend_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, uint32_t log_in, const void *omega_mont_host,
+                         int scale_by_n_inv, const void *g_pre_mont_host, const void *g_post_mont_host, void *hip_stream);
+
 /* a[i] *= g^i, i < 2^log_n */
 int zk_coset_mul(zk_field_t f, void *a_mont_host, uint32_t log_n, const void *g_mont_host);
 int zk_coset_mul_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *g_mont_host, void *hip_stream);

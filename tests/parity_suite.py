@@ -383,6 +383,25 @@ def check_ntt_fused_coset(zk, name, logn, threads=8):
     assert (to_host(zk, zk.coset_mul(name, d, g)) == orc.distribute_powers(name, a, g)).all()
 
 
+def check_ntt_extend(zk, name, log_in, logn, threads=8):
+    """zk_ntt_extend_device: the transform of a zero-extended input (halo2 coeff_to_extended) never reads the padding --
+    the tail of the buffer is filled with garbage here -- and equals the oracle's coset FFT of the padded vector"""
+    n = 1 << logn
+    a = np.zeros((n, 4), dtype=np.uint64)
+    a[:1 << log_in] = rand_field(name, 1 << log_in, 29)
+    w = orc.root_of_unity(name, logn)
+    g = orc.field_generator(name)
+    exp = orc.ark_fft(name, a, "coset_fft", threads=threads)
+    dirty = a.copy()
+    dirty[1 << log_in:] = rand_field(name, n - (1 << log_in), 31) if log_in < logn else dirty[1 << log_in:]
+    got = to_host(zk, zk.halo2.coeff_to_extended(name, to_device(zk, dirty), log_in, w, g))
+    assert (got == exp).all(), (name, log_in, logn)
+    # without the coset shift, with 1/n scaling
+    winv = orc.fe_op(name, "inv", w)
+    got = to_host(zk, zk.ntt(name, to_device(zk, dirty), winv, scale_by_n_inv=True, in_log=log_in, device=True))
+    assert (got == orc.ark_fft(name, a, "ifft", threads=threads)).all(), (name, log_in, logn, "ifft")
+
+
 def check_msm_split(zk, cname, n, window_bits, realistic=True):
     """bucket splitting (every bucket's slice summed by 2^k lanes, then combined) for k = 0..3, including oversized
     buckets (realistic mix) and buckets shorter than the number of pieces"""

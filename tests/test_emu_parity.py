@@ -42,6 +42,15 @@ def test_ntt_multipass(zk, monkeypatch, max_logr, logt):
         ps.check_ntt_vs_oracle(zk, name, logn)
 
 
+def test_ntt_extend(zk, monkeypatch):
+    ps.check_ntt_extend(zk, "PallasFp", 5, 8)        # one pass
+    ps.check_ntt_extend(zk, "Bls381Fr", 9, 12)       # two passes
+    ps.check_ntt_extend(zk, "PallasFp", 0, 6)        # a single coefficient
+    ps.check_ntt_extend(zk, "PallasFq", 7, 7)        # nothing to extend
+    monkeypatch.setenv("ZK_NTT_MAX_LOGR", "3")
+    ps.check_ntt_extend(zk, "Bn254Fr", 4, 8)         # three passes
+
+
 def test_ntt_two_pass_default_plan(zk):
     ps.check_ntt_vs_oracle(zk, "PallasFp", 12)
 

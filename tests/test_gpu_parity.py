@@ -149,6 +149,11 @@ def test_msm_slice_lengths(zk, cname):
     ps.check_msm_slice_lengths(zk, cname, 1 << 13, 12)
 
 
+@pytest.mark.parametrize("name,log_in,logn", [("PallasFp", 10, 13), ("Bls381Fr", 17, 20), ("Bn254Fr", 12, 12), ("PallasFq", 18, 21)])
+def test_ntt_extend(zk, name, log_in, logn):
+    ps.check_ntt_extend(zk, name, log_in, logn, threads=32)
+
+
 @pytest.mark.parametrize("cname", ps.CURVES)
 def test_fixed_base_msm(zk, cname):
     ps.check_fixed_base_msm(zk, cname, 1003)
