@@ -124,3 +124,5 @@ def test_msm_bucket_splitting(zk):
     ps.check_msm_split(zk, "Bls381G1", 150, 4, realistic=False)
     ps.check_msm_split(zk, "Pallas", 3000, 6)        # oversized buckets + splitting
     ps.check_msm_split(zk, "Bn254G2", 60, 3)
+    ps.check_msm_split(zk, "Vesta", 900, 8)          # 128 buckets per range: the size-rank zones exist
+    ps.check_msm_split(zk, "Bn254G1", 2500, 11)      # two ranges of 512 buckets per window
