@@ -202,6 +202,36 @@ def test_msm_full_size_2p20(zk, cname):
     bases.free()
 
 
+def test_msm_2p24_identity(zk):
+    """2^24 points (16x the headline size: u32 entry positions reach 2^28, 1 GB of bases): the size-independent identity
+    MSM(s, [k_i G]) = [sum s_i k_i mod r] G, with the bases from the windowed fixed-base path; whole and window-sharded."""
+    import torch
+    from oracle import pyref
+    cname, n = "Vesta", 1 << 24
+    ks = ps.scalars_for(cname, n, 2024)
+    sc = ps.scalars_for(cname, n, 2025)
+    d_pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    zk.fixed_base_msm_device(cname, torch.from_numpy(ks.view(np.int64)).cuda(), d_pts, n)
+    torch.cuda.synchronize()
+    bases = zk.Bases(cname, device_tensor=d_pts, n=n)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    r = pyref.FIELDS[pyref.CURVES[cname][1]][0]
+    # sum s_i k_i mod r on 64-bit limbs would overflow numpy: Python ints over object arrays, chunked
+    a = sc.astype(object)
+    b = ks.astype(object)
+    sv = a[:, 0] + (a[:, 1] << 64) + (a[:, 2] << 128) + (a[:, 3] << 192)
+    kv = b[:, 0] + (b[:, 1] << 64) + (b[:, 2] << 128) + (b[:, 3] << 192)
+    tot = int((sv * kv).sum() % r)
+    exp = orc.scalar_mul(cname, orc.curve_generator(cname), orc.int_to_limbs(tot, 4))
+    got = zk.point_to_affine(cname, zk.msm(bases, d_sc))
+    assert (got == exp).all()
+    W = zk.msm_window_count(cname, n)
+    lo = zk.msm(bases, d_sc, windows=(0, W // 4))
+    hi = zk.msm(bases, d_sc, windows=(W // 4, W))
+    assert (zk.point_to_affine(cname, zk.point_add(cname, lo, hi)) == exp).all()
+    bases.free()
+
+
 def test_msm_2p22_bn254(zk):
     """BASELINE configs[3] scale: 2^22-point BN254 G1 MSM (Groth16-sized), structural identity + the threaded oracle."""
     import torch
