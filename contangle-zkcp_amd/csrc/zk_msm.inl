@@ -164,14 +164,17 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
                   (const uint16_t*)digits, sh, (const uint32_t*)blockcnt, (const uint32_t*)wg_total, (const uint32_t*)region_base, nblocks,
                   stage_idx, stage_low);
         HIP_TRY(hipEventRecord(ev[2], st));
-        // LDS permutation capacity of a sort workgroup: 1.5x the mean region, at most 24576 entries (57 KB of LDS in all,
-        // two workgroups per CU); larger regions scatter straight to HBM
+        // LDS permutation capacity of a sort workgroup: 1.5x the mean region, at most 24576 entries (61 KB of LDS in all,
+        // two workgroups per CU); larger regions are sorted in chunks of half that
         uint32_t cap = (uint32_t)((n / sh.nranges) * 3 / 2 + 64);
         if (cap > 24576) cap = 24576;
         cap = (cap + 1) & ~1u;
-        ZK_LAUNCH((msm_sort_kernel<void>), nreg, n >= 8192 ? 1024u : 256u, (size_t)(2 * sh.rb + 1024 + 258) * 4 + (size_t)cap * 2, st,
+        // regions up to 4x the mean (large n) are sorted in LDS chunks; anything beyond is a skewed witness's hot region
+        const uint64_t cl64 = 4 * (n / sh.nranges) + 4 * (uint64_t)cap;
+        const uint32_t chunk_limit = cl64 < 0xffffffffull ? (uint32_t)cl64 : 0xffffffffu;
+        ZK_LAUNCH((msm_sort_kernel<void>), nreg, n >= 8192 ? 1024u : 256u, (size_t)(4 * sh.rb + 1024 + 258) * 4 + (size_t)cap * 2, st,
                   (const uint32_t*)stage_idx, (const uint16_t*)stage_low, sh, (const uint32_t*)region_base, (const uint32_t*)wg_total, counts,
-                  offs, order, sorted, cap);
+                  offs, order, sorted, cap, chunk_limit);
         HIP_TRY(hipEventRecord(ev[3], st));
         // ---- persistent accumulate: lanes stream buckets, largest first; oversized buckets go to the cooperative segment
         // kernels (fixed grids over device-side lists, no host round trip)

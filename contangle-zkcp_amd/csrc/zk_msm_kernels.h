@@ -220,23 +220,50 @@ __global__ void __launch_bounds__(1024) msm_stage_kernel(const uint16_t* __restr
     }
 }
 
+constexpr uint32_t MSM_HOT_UNROLL = 8;   // entries per lane and iteration in the hot-region loops of the sort kernel
+
+// atomicAdd(&ctr[key], 1) for every lane with `valid`, returning the value before the lane's increment -- but the lanes of
+// the wave that share the first valid lane's key are served by ONE atomic (ballot + popcount).  For a skewed witness most
+// entries of the hot region carry the same bucket (the unit scalars of a Groth16 assignment): same-address LDS atomics
+// serialise lane by lane, this does not.  Every lane of the wave must call it (wave-uniform trip counts).
+#ifdef ZK_EMU
+#define ZK_READLANE(v, l) __shfl((v), (l))
+#else
+#define ZK_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (l)))   // `l` is wave-uniform here: no LDS round trip
+#endif
+__device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* ctr, uint32_t key, bool valid) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0) return 0;
+    const int leader = __ffsll((unsigned long long)vm) - 1;
+    const uint32_t hot = ZK_READLANE(key, leader);
+    const bool match = valid && key == hot;
+    const uint64_t mm = __ballot(match);
+    uint32_t base = 0;
+    if (lane == (uint32_t)leader) base = atomicAdd(&ctr[hot], (uint32_t)__popcll((unsigned long long)mm));
+    base = ZK_READLANE(base, leader);
+    if (match) return base + (uint32_t)__popcll((unsigned long long)(mm & ((1ull << lane) - 1)));
+    if (valid) return atomicAdd(&ctr[key], 1u);
+    return 0;
+}
+
 // grid = regions; workgroup (w, h) owns buckets [h*rb, (h+1)*rb) of window w and entries [region_base, + wg_total) of the
-// staged and of the sorted array.  LDS: hist[rb] | cur[rb] | part[1024] | bins[258] | perm[cap] (u16).
+// staged and of the sorted array.  LDS: hist[rb] | cur[rb] | part[1024] | bins[258] | coff[rb] | ccur[rb] | perm[cap] (u16).
 // A region of at most `cap` entries is sorted inside LDS -- as a permutation of its entry numbers, 2 bytes each -- and
-// written out as one coalesced stream (sorted[k] = staged[perm[k]], the gather served by L2); scattering 4-byte stores
-// over the region directly, as an oversized region (a skewed witness) still does, costs ~5x the HBM write traffic.
+// written out as one coalesced stream (sorted[k] = staged[perm[k]], the gather served by L2); a larger one in chunks (below).
+// Scattering 4-byte stores over the region directly costs ~5x the HBM write traffic.
 template <class Tag>
 __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t* __restrict__ stage_idx, const uint16_t* __restrict__ stage_low,
                                                         MsmShape sh, const uint32_t* __restrict__ region_base,
                                                         const uint32_t* __restrict__ wg_total, uint32_t* __restrict__ counts,
                                                         uint32_t* __restrict__ offs, uint32_t* __restrict__ order,
-                                                        uint32_t* __restrict__ sorted, uint32_t cap) {
+                                                        uint32_t* __restrict__ sorted, uint32_t cap, uint32_t chunk_limit) {
     ZK_DYN_SHARED(uint32_t, lds);
     uint32_t* hist = lds;
     uint32_t* cur = hist + sh.rb;
     uint32_t* part = cur + sh.rb;
     uint32_t* bins = part + 1024;
-    uint16_t* perm = reinterpret_cast<uint16_t*>(bins + 258);
+    uint16_t* perm = reinterpret_cast<uint16_t*>(bins + 258 + 2 * sh.rb);
     const uint32_t tid = threadIdx.x, nth = blockDim.x;
     const uint32_t w = blockIdx.x / sh.nranges, h = blockIdx.x % sh.nranges;
     const uint64_t gb0 = (uint64_t)w * sh.nbk + (uint64_t)h * sh.rb;
@@ -245,7 +272,22 @@ __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t* __restri
     for (uint32_t j = tid; j < sh.rb; j += nth) hist[j] = 0;
     for (uint32_t j = tid; j < 258; j += nth) bins[j] = 0;
     __syncthreads();
-    for (uint32_t e = tid; e < total; e += nth) atomicAdd(&hist[stage_low[base + e]], 1u);
+    const bool hot = total > chunk_limit;   // far above the mean region: a skewed witness
+    if (hot) {
+        // one workgroup, a third of all entries: MSM_HOT_UNROLL loads in flight per lane, or every entry costs a memory latency
+        for (uint32_t e0 = 0; e0 < total; e0 += nth * MSM_HOT_UNROLL) {
+            uint32_t lows[MSM_HOT_UNROLL];
+            ZK_UNROLL
+            for (uint32_t u = 0; u < MSM_HOT_UNROLL; u++) {
+                const uint32_t e = e0 + u * nth + tid;
+                lows[u] = e < total ? (uint32_t)stage_low[base + e] : 0xffffffffu;
+            }
+            ZK_UNROLL
+            for (uint32_t u = 0; u < MSM_HOT_UNROLL; u++) wave_agg_inc(hist, lows[u], lows[u] != 0xffffffffu);
+        }
+    } else {
+        for (uint32_t e = tid; e < total; e += nth) atomicAdd(&hist[stage_low[base + e]], 1u);
+    }
     __syncthreads();
     // exclusive scan of this range's counts: per-lane chunk sums, Hillis-Steele over the lanes, then refill
     const uint32_t per = (sh.rb + nth - 1) / nth;
@@ -298,9 +340,73 @@ __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t* __restri
         __syncthreads();
         for (uint32_t k = tid; k < total; k += nth) sorted[base + k] = stage_idx[base + perm[k]];
     } else {
-        for (uint32_t e = tid; e < total; e += nth) {
-            const uint32_t p = atomicAdd(&cur[stage_low[base + e]], 1u);
-            sorted[base + p] = stage_idx[base + e];
+        if (hot) {
+            // (a skewed witness: the unit scalars of a Groth16 assignment all land in one bucket) this workgroup is the
+            // critical path of the launch: wave-aggregated cursors, stores straight to their places
+            for (uint32_t e0 = 0; e0 < total; e0 += nth * MSM_HOT_UNROLL) {
+                uint32_t lows[MSM_HOT_UNROLL], vals[MSM_HOT_UNROLL];
+                ZK_UNROLL
+                for (uint32_t u = 0; u < MSM_HOT_UNROLL; u++) {
+                    const uint32_t e = e0 + u * nth + tid;
+                    lows[u] = e < total ? (uint32_t)stage_low[base + e] : 0xffffffffu;
+                    vals[u] = e < total ? stage_idx[base + e] : 0u;
+                }
+                ZK_UNROLL
+                for (uint32_t u = 0; u < MSM_HOT_UNROLL; u++) {
+                    const bool valid = lows[u] != 0xffffffffu;
+                    const uint32_t p = wave_agg_inc(cur, lows[u], valid);
+                    if (valid) sorted[base + p] = vals[u];
+                }
+            }
+            return;
+        }
+        // A region larger than the permutation buffer because n is large (>= 2^22) is sorted in chunks of cap / 2
+        // entries: each chunk is counting-sorted inside LDS (entry number + bucket per sorted position) and every bucket's
+        // run of the chunk is appended at the bucket's running position cur[] -- runs of chunk / rb entries instead of
+        // single 4-byte stores.
+        uint32_t* coff = bins + 258;          // exclusive offsets of the chunk's buckets
+        uint32_t* ccur = coff + sh.rb;        // counts, then cursors
+        uint16_t* cperm = perm;               // entry number inside the chunk, by sorted position
+        const uint32_t ccap = cap >> 1;
+        uint16_t* cbkt = perm + ccap;         // bucket of the sorted position
+        for (uint32_t c0 = 0; c0 < total; c0 += ccap) {
+            const uint32_t clen = total - c0 < ccap ? total - c0 : ccap;
+            for (uint32_t j = tid; j < sh.rb; j += nth) ccur[j] = 0;
+            __syncthreads();
+            for (uint32_t e = tid; e < clen; e += nth) atomicAdd(&ccur[stage_low[base + c0 + e]], 1u);
+            __syncthreads();
+            uint32_t csum = 0;
+            for (uint32_t j = jlo; j < jhi; j++) csum += ccur[j];
+            part[tid] = csum;
+            __syncthreads();
+            for (uint32_t d = 1; d < nth; d <<= 1) {
+                const uint32_t v = tid >= d ? part[tid - d] : 0;
+                __syncthreads();
+                part[tid] += v;
+                __syncthreads();
+            }
+            uint32_t crun = part[tid] - csum;
+            for (uint32_t j = jlo; j < jhi; j++) {
+                const uint32_t cnt = ccur[j];
+                coff[j] = crun;
+                ccur[j] = crun;
+                crun += cnt;
+            }
+            __syncthreads();
+            for (uint32_t e = tid; e < clen; e += nth) {
+                const uint32_t j = stage_low[base + c0 + e];
+                const uint32_t p = atomicAdd(&ccur[j], 1u);
+                cperm[p] = (uint16_t)e;
+                cbkt[p] = (uint16_t)j;
+            }
+            __syncthreads();
+            for (uint32_t p = tid; p < clen; p += nth) {
+                const uint32_t j = cbkt[p];
+                sorted[base + cur[j] + (p - coff[j])] = stage_idx[base + c0 + cperm[p]];
+            }
+            __syncthreads();
+            for (uint32_t j = jlo; j < jhi; j++) cur[j] += ccur[j] - coff[j];
+            __syncthreads();
         }
     }
 }

@@ -34,10 +34,50 @@ void trampoline() {
 }
 }  // namespace
 
-void syncthreads() {
+static void yield() {
     Fiber* f = g_running;
     swapcontext(&f->ctx, &sched_ctx);
     cur = &f->tc;
+}
+
+// counting barrier over the fibers of the workgroup that are still alive (a lane that has returned no longer takes part,
+// as on the hardware)
+static unsigned g_alive = 0, g_arrived = 0, g_gen = 0;
+static void barrier_release_if_complete() {
+    if (g_arrived > 0 && g_arrived >= g_alive) {
+        g_arrived = 0;
+        g_gen++;
+    }
+}
+void syncthreads() {
+    const unsigned gen = g_gen;
+    g_arrived++;
+    barrier_release_if_complete();
+    while (g_gen == gen) yield();
+}
+
+// per-wave rendezvous with a one-word payload per lane
+namespace {
+struct WaveState {
+    uint32_t in[64], out[64];
+    unsigned arrived, gen;
+};
+std::vector<WaveState> waves;
+}  // namespace
+const uint32_t* wave_exchange(uint32_t v) {
+    const unsigned tid = g_running->tc.tid.x, w = tid / 64, lane = tid % 64;
+    WaveState& ws = waves[w];
+    const unsigned lanes = g_block_dim.x - 64 * w < 64 ? g_block_dim.x - 64 * w : 64;
+    const unsigned gen = ws.gen;
+    ws.in[lane] = v;
+    if (++ws.arrived == lanes) {
+        for (unsigned i = 0; i < 64; i++) ws.out[i] = i < lanes ? ws.in[i] : 0;
+        ws.arrived = 0;
+        ws.gen++;
+    } else {
+        while (ws.gen == gen) yield();
+    }
+    return ws.out;
 }
 
 static int g_count_acc = 0;
@@ -58,6 +98,7 @@ void launch(unsigned grid, unsigned block, size_t shmem, const std::function<voi
     std::vector<char> smem(shmem + 64);
     g_dyn_smem = smem.data() + ((64 - ((uintptr_t)smem.data() & 63)) & 63);
     if (fibers.size() < block) fibers.resize(block);
+    if (waves.size() < (block + 63) / 64) waves.resize((block + 63) / 64);
     if (stacks.size() < (size_t)block * kStack) stacks.resize((size_t)block * kStack);
     g_body = &body;
     for (unsigned b = 0; b < grid; b++) {
@@ -73,6 +114,9 @@ void launch(unsigned grid, unsigned block, size_t shmem, const std::function<voi
             makecontext(&f.ctx, trampoline, 0);
         }
         unsigned remaining = block;
+        g_alive = block;
+        g_arrived = 0;
+        for (auto& ws : waves) ws.arrived = 0;
         while (remaining) {
             for (unsigned t = 0; t < block; t++) {
                 Fiber& f = fibers[t];
@@ -80,7 +124,11 @@ void launch(unsigned grid, unsigned block, size_t shmem, const std::function<voi
                 g_running = &f;
                 cur = &f.tc;
                 swapcontext(&sched_ctx, &f.ctx);
-                if (f.done) remaining--;
+                if (f.done) {
+                    remaining--;
+                    g_alive--;
+                    barrier_release_if_complete();   // the lanes still at a barrier no longer wait for this one
+                }
             }
         }
     }

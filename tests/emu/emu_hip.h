@@ -1,8 +1,8 @@
 // TEST INFRASTRUCTURE -- a minimal HIP-semantics emulator so that `pytest -m "not gpu"` (no GPU
 // in the build container) and CPU sanitizers can execute the kernel sources of
 // contangle-zkcp_amd/csrc unchanged: each workgroup runs as a set of cooperative fibers
-// (ucontext), `__syncthreads()` is a fiber barrier, `__shared__` is static storage, atomics are
-// plain read-modify-writes (fibers never run concurrently).
+// (ucontext), `__syncthreads()` is a counting fiber barrier, `__ballot` / `__shfl` are per-wave rendezvous,
+// `__shared__` is static storage, atomics are plain read-modify-writes (fibers never run concurrently).
 //
 // It is NOT a backend: nothing in the product loads tests/emu/libzkcp_emu.so, bench.py and
 // __graft_entry__.smoke() never touch it, and the product library fails with ZK_ERR_NO_DEVICE
@@ -28,6 +28,10 @@ extern char* g_dyn_smem;
 void launch(unsigned grid, unsigned block, size_t shmem, const std::function<void()>& body);
 void syncthreads();
 int syncthreads_count(int pred);
+// wave-level rendezvous: every lane of the calling lane's 64-wide wave (the lanes of the workgroup's last wave if it is
+// short) contributes one word; returns the wave's 64 words (valid until the wave's next exchange).  Like the hardware
+// cross-lane operations it requires all those lanes to reach the call.
+const uint32_t* wave_exchange(uint32_t v);
 }  // namespace emu
 
 #define threadIdx (emu::cur->tid)
@@ -67,6 +71,15 @@ static inline uint32_t __brev(uint32_t x) {
 }
 static inline int __clz(uint32_t x) { return x ? __builtin_clz(x) : 32; }
 static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
+static inline int __popcll(uint64_t x) { return __builtin_popcountll(x); }
+static inline int __ffsll(uint64_t x) { return __builtin_ffsll((long long)x); }
+static inline uint64_t __ballot(int pred) {
+    const uint32_t* w = emu::wave_exchange(pred ? 1u : 0u);
+    uint64_t m = 0;
+    for (int i = 0; i < 64; i++) m |= (uint64_t)(w[i] & 1u) << i;
+    return m;
+}
+static inline uint32_t __shfl(uint32_t v, int src_lane) { return emu::wave_exchange(v)[src_lane & 63]; }
 
 // ---- host runtime shims (device memory == host memory) ----
 typedef int hipError_t;

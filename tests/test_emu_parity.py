@@ -75,7 +75,8 @@ def test_msm_edges(zk, cname):
 
 @pytest.mark.parametrize("cname,n,wb,realistic", [
     ("Pallas", 300, 0, False), ("Vesta", 257, 6, True), ("Bn254G1", 200, 5, False), ("Bls381G1", 150, 7, True),
-    ("Pallas", 1024, 8, True), ("Bls381G2", 120, 5, False), ("Bn254G2", 100, 6, True)])
+    ("Pallas", 1024, 8, True), ("Bls381G2", 120, 5, False), ("Bn254G2", 100, 6, True),
+    ("Vesta", 3000, 16, True)])      # 64 ranges per window: the unit scalars make one region 20x the mean (wave-aggregated path)
 def test_msm_vs_oracle(zk, cname, n, wb, realistic):
     ps.check_msm_vs_oracle(zk, cname, n, wb, realistic)
 
