@@ -89,7 +89,7 @@ API int zk_shutdown(void) {
     for (auto& kv : g.tw) hipFree(kv.second.dev);
     g.tw.clear();
     g.tw_bytes = 0;
-    for (DevBuf* b : {&g.ntt_tmp, &g.pow_tbl, &g.fb_table, &g.fb_tmp, &g.msm_counts, &g.msm_digits, &g.msm_blockcnt, &g.msm_stage_idx, &g.msm_stage_low, &g.msm_queue, &g.msm_seg_out, &g.msm_subacc, &g.msm_sorted, &g.msm_buckets, &g.msm_part_a, &g.msm_part_b,
+    for (DevBuf* b : {&g.ntt_tmp, &g.pow_tbl, &g.fb_table, &g.fb_tmp, &g.msm_hot, &g.msm_counts, &g.msm_digits, &g.msm_blockcnt, &g.msm_stage_idx, &g.msm_stage_low, &g.msm_queue, &g.msm_seg_out, &g.msm_subacc, &g.msm_sorted, &g.msm_buckets, &g.msm_part_a, &g.msm_part_b,
                       &g.scratch_in, &g.scratch_out})
         ws_free(*b);
     if (g.have_events) {

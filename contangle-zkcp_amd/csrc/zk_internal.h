@@ -74,7 +74,7 @@ struct Ctx {
     uint64_t tw_stamp = 0;
     size_t tw_bytes = 0;
     // workspaces (grow-only, reused across calls)
-    DevBuf ntt_tmp, pow_tbl, fb_table, fb_tmp, msm_counts, msm_digits, msm_blockcnt, msm_stage_idx, msm_stage_low, msm_queue, msm_seg_out, msm_subacc, msm_sorted, msm_buckets, msm_part_a, msm_part_b, scratch_in, scratch_out;
+    DevBuf ntt_tmp, pow_tbl, fb_table, fb_tmp, msm_hot, msm_counts, msm_digits, msm_blockcnt, msm_stage_idx, msm_stage_low, msm_queue, msm_seg_out, msm_subacc, msm_sorted, msm_buckets, msm_part_a, msm_part_b, scratch_in, scratch_out;
     hipEvent_t ev[6];   // MSM phase events
     bool have_events = false;
     zk_msm_profile prof;

@@ -172,9 +172,32 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         // regions up to 4x the mean (large n) are sorted in LDS chunks; anything beyond is a skewed witness's hot region
         const uint64_t cl64 = 4 * (n / sh.nranges) + 4 * (uint64_t)cap;
         const uint32_t chunk_limit = cl64 < 0xffffffffull ? (uint32_t)cl64 : 0xffffffffu;
+        // hot regions (skewed witnesses) are histogrammed and scattered by MSM_HOT_SLICES workgroups each, around the sort kernel
+        const bool hot_help = nreg <= 1024 && !getenv("ZK_MSM_NO_HOT_HELP");
+        uint32_t* hot_flag = nullptr;
+        uint32_t* hot_list = nullptr;
+        uint32_t* gcur = nullptr;
+        uint32_t hot_slices = (uint32_t)(n >> 16);
+        if (hot_slices < 1) hot_slices = 1;
+        if (hot_slices > MSM_HOT_SLICES) hot_slices = MSM_HOT_SLICES;
+        if (hot_help) {
+            ZK_TRY(ws_get(g.msm_hot, ((size_t)nreg + 1 + MSM_HOT_MAX + nbuckets) * 4));
+            hot_flag = (uint32_t*)g.msm_hot.p;
+            hot_list = hot_flag + nreg;
+            gcur = hot_list + 1 + MSM_HOT_MAX;
+            HIP_TRY(hipMemsetAsync(counts, 0, (size_t)nbuckets * 4, st));
+            ZK_LAUNCH((msm_hot_list_kernel<void>), 1, 1024, 0, st, (const uint32_t*)wg_total, nreg, chunk_limit, hot_flag, hot_list);
+            ZK_LAUNCH((msm_hot_kernel<void>), MSM_HOT_MAX * hot_slices, 1024, (size_t)2 * sh.rb * 4, st, (const uint32_t*)stage_idx,
+                      (const uint16_t*)stage_low, sh, (const uint32_t*)region_base, (const uint32_t*)wg_total, (const uint32_t*)hot_list, counts,
+                      gcur, sorted, 0, hot_slices);
+        }
         ZK_LAUNCH((msm_sort_kernel<void>), nreg, n >= 8192 ? 1024u : 256u, (size_t)(4 * sh.rb + 1024 + 258) * 4 + (size_t)cap * 2, st,
                   (const uint32_t*)stage_idx, (const uint16_t*)stage_low, sh, (const uint32_t*)region_base, (const uint32_t*)wg_total, counts,
-                  offs, order, sorted, cap, chunk_limit);
+                  offs, order, sorted, cap, chunk_limit, (const uint32_t*)hot_flag, gcur);
+        if (hot_help)
+            ZK_LAUNCH((msm_hot_kernel<void>), MSM_HOT_MAX * hot_slices, 1024, (size_t)2 * sh.rb * 4, st, (const uint32_t*)stage_idx,
+                      (const uint16_t*)stage_low, sh, (const uint32_t*)region_base, (const uint32_t*)wg_total, (const uint32_t*)hot_list, counts,
+                      gcur, sorted, 1, hot_slices);
         HIP_TRY(hipEventRecord(ev[3], st));
         // ---- persistent accumulate: lanes stream buckets, largest first; oversized buckets go to the cooperative segment
         // kernels (fixed grids over device-side lists, no host round trip)

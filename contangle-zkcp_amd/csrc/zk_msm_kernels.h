@@ -247,6 +247,90 @@ __device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* ctr, uint32_t key, bo
     return 0;
 }
 
+// ---- hot regions (far above the mean: a skewed witness) are histogrammed and scattered by many workgroups ----
+constexpr uint32_t MSM_HOT_MAX = 8;       // hot regions served this way (the rest stay with their own sort workgroup)
+constexpr uint32_t MSM_HOT_SLICES = 32;   // workgroups per hot region at most (n / 65536 of them for smaller inputs)
+
+// one workgroup: hot_flag[r] = 1 + rank for the first MSM_HOT_MAX regions with more than chunk_limit entries (0 otherwise),
+// hot_list[0] = their number, hot_list[1 + k] = the region of rank k.  nreg <= 1024.
+template <class Tag>
+__global__ void __launch_bounds__(1024) msm_hot_list_kernel(const uint32_t* __restrict__ wg_total, uint32_t nreg, uint32_t chunk_limit,
+                                                            uint32_t* __restrict__ hot_flag, uint32_t* __restrict__ hot_list) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint32_t f = (tid < nreg && wg_total[tid] > chunk_limit) ? 1u : 0u;
+    part[tid] = f;
+    __syncthreads();
+    for (uint32_t d = 1; d < nth; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t rank = part[tid] - f;
+    if (tid < nreg) hot_flag[tid] = (f && rank < MSM_HOT_MAX) ? rank + 1 : 0u;
+    if (f && rank < MSM_HOT_MAX) hot_list[1 + rank] = tid;
+    if (tid == nth - 1) hot_list[0] = part[tid] < MSM_HOT_MAX ? part[tid] : MSM_HOT_MAX;
+}
+
+// grid = MSM_HOT_MAX * slices; workgroup (k, s) takes slice s of the hot region of rank k: an LDS histogram of the
+// slice (wave-aggregated), then  phase 0: counts[bucket] += slice count (global atomics, one per non-empty bucket)
+//                                phase 1: reserve the slice's run of every bucket at gcur[bucket], scatter through LDS cursors
+// LDS: hist[rb] | cur[rb]
+template <class Tag>
+__global__ void __launch_bounds__(1024) msm_hot_kernel(const uint32_t* __restrict__ stage_idx, const uint16_t* __restrict__ stage_low,
+                                                       MsmShape sh, const uint32_t* __restrict__ region_base,
+                                                       const uint32_t* __restrict__ wg_total, const uint32_t* __restrict__ hot_list,
+                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ gcur,
+                                                       uint32_t* __restrict__ sorted, int phase, uint32_t slices) {
+    ZK_DYN_SHARED(uint32_t, lds);
+    uint32_t* hist = lds;
+    uint32_t* cur = hist + sh.rb;
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint32_t k = blockIdx.x / slices, sl = blockIdx.x % slices;
+    if (k >= hot_list[0]) return;
+    const uint32_t r = hot_list[1 + k];
+    const uint32_t base = region_base[r], total = wg_total[r];
+    const uint32_t len = (total + slices - 1) / slices;
+    const uint32_t lo = sl * len < total ? sl * len : total, hi = lo + len < total ? lo + len : total;
+    const uint64_t gb0 = (uint64_t)r * sh.rb;     // regions are consecutive runs of rb buckets
+    for (uint32_t j = tid; j < sh.rb; j += nth) hist[j] = 0;
+    __syncthreads();
+    for (uint32_t e0 = lo; e0 < hi; e0 += nth * MSM_HOT_UNROLL) {
+        uint32_t lows[MSM_HOT_UNROLL];
+        ZK_UNROLL
+        for (uint32_t u = 0; u < MSM_HOT_UNROLL; u++) {
+            const uint32_t e = e0 + u * nth + tid;
+            lows[u] = e < hi ? (uint32_t)stage_low[base + e] : 0xffffffffu;
+        }
+        ZK_UNROLL
+        for (uint32_t u = 0; u < MSM_HOT_UNROLL; u++) wave_agg_inc(hist, lows[u], lows[u] != 0xffffffffu);
+    }
+    __syncthreads();
+    if (phase == 0) {
+        for (uint32_t j = tid; j < sh.rb; j += nth)
+            if (hist[j]) atomicAdd(&counts[gb0 + j], hist[j]);
+        return;
+    }
+    for (uint32_t j = tid; j < sh.rb; j += nth) cur[j] = hist[j] ? atomicAdd(&gcur[gb0 + j], hist[j]) : 0u;
+    __syncthreads();
+    for (uint32_t e0 = lo; e0 < hi; e0 += nth * MSM_HOT_UNROLL) {
+        uint32_t lows[MSM_HOT_UNROLL], vals[MSM_HOT_UNROLL];
+        ZK_UNROLL
+        for (uint32_t u = 0; u < MSM_HOT_UNROLL; u++) {
+            const uint32_t e = e0 + u * nth + tid;
+            lows[u] = e < hi ? (uint32_t)stage_low[base + e] : 0xffffffffu;
+            vals[u] = e < hi ? stage_idx[base + e] : 0u;
+        }
+        ZK_UNROLL
+        for (uint32_t u = 0; u < MSM_HOT_UNROLL; u++) {
+            const bool valid = lows[u] != 0xffffffffu;
+            const uint32_t p = wave_agg_inc(cur, lows[u], valid);
+            if (valid) sorted[p] = vals[u];
+        }
+    }
+}
+
 // grid = regions; workgroup (w, h) owns buckets [h*rb, (h+1)*rb) of window w and entries [region_base, + wg_total) of the
 // staged and of the sorted array.  LDS: hist[rb] | cur[rb] | part[1024] | bins[258] | coff[rb] | ccur[rb] | perm[cap] (u16).
 // A region of at most `cap` entries is sorted inside LDS -- as a permutation of its entry numbers, 2 bytes each -- and
@@ -257,7 +341,8 @@ __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t* __restri
                                                         MsmShape sh, const uint32_t* __restrict__ region_base,
                                                         const uint32_t* __restrict__ wg_total, uint32_t* __restrict__ counts,
                                                         uint32_t* __restrict__ offs, uint32_t* __restrict__ order,
-                                                        uint32_t* __restrict__ sorted, uint32_t cap, uint32_t chunk_limit) {
+                                                        uint32_t* __restrict__ sorted, uint32_t cap, uint32_t chunk_limit,
+                                                        const uint32_t* __restrict__ hot_flag, uint32_t* __restrict__ gcur) {
     ZK_DYN_SHARED(uint32_t, lds);
     uint32_t* hist = lds;
     uint32_t* cur = hist + sh.rb;
@@ -273,7 +358,10 @@ __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t* __restri
     for (uint32_t j = tid; j < 258; j += nth) bins[j] = 0;
     __syncthreads();
     const bool hot = total > chunk_limit;   // far above the mean region: a skewed witness
-    if (hot) {
+    const bool helped = hot && hot_flag != nullptr && hot_flag[blockIdx.x] != 0;   // msm_hot_kernel histograms and scatters it
+    if (helped) {
+        for (uint32_t j = tid; j < sh.rb; j += nth) hist[j] = counts[gb0 + j];
+    } else if (hot) {
         // one workgroup, a third of all entries: MSM_HOT_UNROLL loads in flight per lane, or every entry costs a memory latency
         for (uint32_t e0 = 0; e0 < total; e0 += nth * MSM_HOT_UNROLL) {
             uint32_t lows[MSM_HOT_UNROLL];
@@ -340,6 +428,11 @@ __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t* __restri
         __syncthreads();
         for (uint32_t k = tid; k < total; k += nth) sorted[base + k] = stage_idx[base + perm[k]];
     } else {
+        if (helped) {
+            // the slices of this region are scattered by msm_hot_kernel (phase 1) from these bucket cursors
+            for (uint32_t j = tid; j < sh.rb; j += nth) gcur[gb0 + j] = base + cur[j];
+            return;
+        }
         if (hot) {
             // (a skewed witness: the unit scalars of a Groth16 assignment all land in one bucket) this workgroup is the
             // critical path of the launch: wave-aggregated cursors, stores straight to their places
