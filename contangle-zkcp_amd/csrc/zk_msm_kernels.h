@@ -756,22 +756,26 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restric
     const XYZZ<C>* src = buckets + (uint64_t)w * nbk + (uint64_t)t * L;
     const uint32_t avail = nbk - t * L < L ? nbk - t * L : L;   // the last slice of a window may be short
     if (avail > 0) b = src[avail - 1];
-    // multiplier phase: wsum += [t * L] run.  2-bit windows over t (run, 2 run, 3 run precomputed: 3 steps per two bits
-    // instead of 4), then log2(L) doublings (L is a power of two whenever it is > 1).  Step counts are uniform over the grid.
+    // multiplier phase: wsum += [t * L] run.  WB-bit windows over t: for WB = 2, run, 2 run, 3 run are precomputed and two
+    // bits cost 3 steps instead of 4 (the G1 point types; the wide G2 ones would spill the two extra points and keep WB = 1);
+    // then log2(L) doublings (L is a power of two whenever it is > 1).  Step counts are uniform over the grid.
+    constexpr uint32_t WB = sizeof(XYZZ<C>) <= 256 ? 2u : 1u;
+    constexpr uint32_t PRE = WB == 2 ? 2u : 0u;
     const uint32_t tmax = slices_per_window - 1;
-    const uint32_t tbits = tmax ? 32u - (uint32_t)__clz(tmax) : 0u;
-    const uint32_t ndig = (tbits + 1) / 2;
     const uint32_t log_l = 31u - (uint32_t)__clz(L);
     const bool pow2 = (L & (L - 1)) == 0;
     const uint32_t mult = pow2 ? t : t * L;                       // multiplier scanned by the digit loop
-    const uint32_t mbits = pow2 ? tbits : (tmax ? 32u - (uint32_t)__clz(tmax * L) : 0u);
-    const uint32_t mdig = pow2 ? ndig : (mbits + 1) / 2;
+    const uint32_t mmax = pow2 ? tmax : tmax * L;
+    const uint32_t mbits = mmax ? 32u - (uint32_t)__clz(mmax) : 0u;
+    const uint32_t mdig = (mbits + WB - 1) / WB;
     const uint32_t tail = pow2 ? log_l : 0u;
     const uint32_t s_mul = 2 * L;                                 // first step of the multiplier phase
-    const uint32_t nsteps = mdig ? s_mul + 2 + 3 * mdig + tail + 1 : s_mul;
+    const uint32_t nsteps = mdig ? s_mul + PRE + (WB + 1) * mdig + tail + 1 : s_mul;
     XYZZ<C> t2, t3;
-    xyzz_set_inf(t2);
-    xyzz_set_inf(t3);
+    if constexpr (WB == 2) {
+        xyzz_set_inf(t2);
+        xyzz_set_inf(t3);
+    }
 #pragma unroll 1
     for (uint32_t s = 0; s < nsteps; s++) {
         XYZZ<C> X, Y;
@@ -790,26 +794,30 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restric
                 X = wsum;
                 Y = run;
             }
-        } else if (s == s_mul) {             // t2 = 2 run
+        } else if (WB == 2 && s == s_mul) {             // t2 = 2 run
             kind = 3;
             X = run;
             Y = run;
             dbl = true;
-        } else if (s == s_mul + 1) {         // t3 = t2 + run
+        } else if (WB == 2 && s == s_mul + 1) {         // t3 = t2 + run
             kind = 4;
-            X = t2;
+            if constexpr (WB == 2) X = t2;
             Y = run;
-        } else if (s < s_mul + 2 + 3 * mdig) {
-            const uint32_t j = s - s_mul - 2, dg = mdig - 1 - j / 3, ph = j % 3;
+        } else if (s < s_mul + PRE + (WB + 1) * mdig) {
+            const uint32_t j = s - s_mul - PRE, dg = mdig - 1 - j / (WB + 1), ph = j % (WB + 1);
             kind = 2;
             X = acc;
-            if (ph < 2) {
+            if (ph < WB) {
                 Y = acc;
                 dbl = true;
             } else {
-                const uint32_t v = (mult >> (2 * dg)) & 3u;
+                const uint32_t v = (mult >> (WB * dg)) & ((1u << WB) - 1);
                 on = v != 0;
-                Y = v == 1 ? run : (v == 2 ? t2 : t3);
+                Y = run;
+                if constexpr (WB == 2) {
+                    if (v == 2) Y = t2;
+                    if (v == 3) Y = t3;
+                }
             }
         } else if (s < nsteps - 1) {         // acc = L * acc
             kind = 2;
@@ -830,10 +838,12 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const XYZZ<C>* __restric
             wsum = X;
         else if (kind == 2)
             acc = X;
-        else if (kind == 3)
-            t2 = X;
-        else
-            t3 = X;
+        else if constexpr (WB == 2) {
+            if (kind == 3)
+                t2 = X;
+            else
+                t3 = X;
+        }
     }
     out[gt] = wsum;
 }
