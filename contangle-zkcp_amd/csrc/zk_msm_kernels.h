@@ -29,7 +29,8 @@ namespace zk {
 //   7. msm_sum_kernel        per-window tree sums of X_t
 //   host: <= a few points per window, Horner over windows (c doublings each).
 // Digits are in [-(2^(c-1)-1), 2^(c-1)]; bucket index b-1 (b = |digit| in 1..2^(c-1)) holds the sum of
-// (+-)P_i.  No global atomics in the sort: every counter lives in LDS, and both sorting steps permute inside LDS and
+// (+-)P_i.  No global atomics in the sort of a uniform input (msm_hot_kernel, for the hot regions of skewed witnesses, issues
+// one per slice and non-empty bucket): every counter lives in LDS, and both sorting steps permute inside LDS and
 // store contiguous chunks.  Every digit is touched four times (digit, stage, histogram, scatter) whatever the number
 // of ranges -- the first version had each (window, range) workgroup filter the whole digit row of its window (16 x
 // redundant at c = 16) and scatter 4-byte stores across its region.
