@@ -31,7 +31,9 @@ EXPORTS = [
     "zk_bases_free", "zk_msm", "zk_msm_device", "zk_msm_last_profile", "zk_ntt", "zk_ntt_device", "zk_coset_mul",
     "zk_coset_mul_device", "zk_ntt_coset_device", "zk_field_root_of_unity", "zk_field_multiplicative_generator", "zk_field_inverse",
     "zk_point_add", "zk_point_to_affine", "zk_fixed_base_mul_device", "zk_vec_op_device", "zk_groth16_witness_map_device",
-    "zk_fixed_base_msm_device", "zk_ntt_extend_device",
+    "zk_fixed_base_msm_device", "zk_ntt_extend_device", "zk_init_devices", "zk_device_count", "zk_msm_submit", "zk_msm_collect",
+    "zk_msm_batch_device", "zk_ntt_configure", "zk_msm_profile_totals", "zk_ntt_profile_enable", "zk_ntt_profile_read",
+    "zk_field_modulus", "zk_vec_scale_periodic_device",
 ]
 
 
@@ -42,14 +44,36 @@ class ZkError(RuntimeError):
 
 
 class MsmOpts(ctypes.Structure):
+    """zk_msm_opts: zero = defaults.  split_log_plus1 = k + 1 forces 2^k pieces per bucket."""
     _fields_ = [("window_bits", ctypes.c_int), ("window_begin", ctypes.c_int), ("window_end", ctypes.c_int),
+                ("limb_bits", ctypes.c_int), ("split_log_plus1", ctypes.c_int), ("slice_len", ctypes.c_int),
+                ("big_threshold", ctypes.c_int), ("waves_per_simd", ctypes.c_int), ("flags", ctypes.c_int),
+                ("reserved", ctypes.c_int * 3)]
+
+
+MSM_FLAG_NO_HOT_HELP = 1
+
+
+class NttOpts(ctypes.Structure):
+    _fields_ = [("max_log_radix", ctypes.c_int), ("log_tile_plus1", ctypes.c_int), ("block", ctypes.c_int),
                 ("reserved", ctypes.c_int)]
 
 
 class MsmProfile(ctypes.Structure):
     _fields_ = [(k, ctypes.c_float) for k in ("digits_ms", "hist_ms", "scatter_ms", "accumulate_ms", "reduce_ms",
                                               "host_tail_ms", "total_ms")] + \
-               [(k, ctypes.c_int) for k in ("window_bits", "windows_total", "windows_done", "groups", "limb_bits")]
+               [(k, ctypes.c_int) for k in ("window_bits", "windows_total", "windows_done", "groups", "limb_bits")] + \
+               [("accumulate_kernel_ms", ctypes.c_float), ("reserved", ctypes.c_int)]
+
+
+class MsmTotals(ctypes.Structure):
+    _fields_ = [("msms", ctypes.c_uint64)] + [(k, ctypes.c_double) for k in (
+        "accumulate_kernel_ms", "accumulate_ms", "sort_ms", "reduce_ms", "host_tail_ms", "device_ms", "algorithmic_bytes")]
+
+
+class NttTotals(ctypes.Structure):
+    _fields_ = [("transforms", ctypes.c_uint64), ("launches", ctypes.c_uint64), ("kernel_ms", ctypes.c_double),
+                ("algorithmic_bytes", ctypes.c_double)]
 
 
 _lib = None
@@ -73,6 +97,15 @@ def load(path=None):
     lib.zk_msm.argtypes = [i32, u64, vp, u64, i32, ctypes.POINTER(MsmOpts), vp]
     lib.zk_msm_device.argtypes = [i32, u64, vp, u64, i32, ctypes.POINTER(MsmOpts), vp, vp]
     lib.zk_msm_last_profile.argtypes = [ctypes.POINTER(MsmProfile)]
+    lib.zk_msm_submit.argtypes = [i32, u64, vp, u64, i32, ctypes.POINTER(MsmOpts), vp, ctypes.POINTER(u64)]
+    lib.zk_msm_collect.argtypes = [u64, vp]
+    lib.zk_msm_batch_device.argtypes = [i32, u64, vp, u64, ctypes.c_uint32, u64, i32, ctypes.POINTER(MsmOpts), vp, vp]
+    lib.zk_init_devices.argtypes = [i32, ctypes.POINTER(i32)]
+    lib.zk_ntt_configure.argtypes = [ctypes.POINTER(NttOpts)]
+    lib.zk_msm_profile_totals.argtypes = [ctypes.POINTER(MsmTotals), i32]
+    lib.zk_ntt_profile_read.argtypes = [ctypes.POINTER(NttTotals)]
+    lib.zk_field_modulus.argtypes = [i32, vp]
+    lib.zk_vec_scale_periodic_device.argtypes = [i32, vp, u64, vp, ctypes.c_uint32, vp]
     lib.zk_ntt.argtypes = [i32, vp, ctypes.c_uint32, vp, i32]
     lib.zk_ntt_device.argtypes = [i32, vp, ctypes.c_uint32, vp, i32, vp]
     lib.zk_ntt_coset_device.argtypes = [i32, vp, ctypes.c_uint32, vp, i32, vp, vp, vp]
@@ -106,6 +139,22 @@ def _check(status, what):
 
 def init(device_id=0):
     _check(load().zk_init(device_id), "zk_init")
+
+
+def init_devices(device_ids):
+    """one process drives several GPUs: bases go to every device, whole MSMs are split over them by scalar window"""
+    ids = (ctypes.c_int * len(device_ids))(*device_ids)
+    _check(load().zk_init_devices(len(device_ids), ids), "zk_init_devices")
+
+
+def device_count():
+    return load().zk_device_count()
+
+
+def ntt_configure(max_log_radix=0, log_tile=None, block=0):
+    """process-wide NTT plan knobs (tuning harness / tests); no arguments restores the defaults"""
+    o = NttOpts(max_log_radix, 0 if log_tile is None else log_tile + 1, block, 0)
+    _check(load().zk_ntt_configure(ctypes.byref(o)), "zk_ntt_configure")
 
 
 def shutdown():
@@ -146,6 +195,13 @@ def base_limbs(curve):
 
 def scalar_field(curve):
     return load().zk_curve_scalar_field(curve_id(curve))
+
+
+def field_modulus(field):
+    """the field's prime as a Python int"""
+    out = np.zeros(4, dtype=np.uint64)
+    _check(load().zk_field_modulus(field_id(field), _ptr(out)), "zk_field_modulus")
+    return sum(int(w) << (64 * i) for i, w in enumerate(out.tolist()))
 
 
 def root_of_unity(field, log_n):
@@ -219,16 +275,30 @@ class Bases:
             pass
 
 
-def msm(bases, scalars, montgomery=False, window_bits=0, windows=None, stream=0):
+def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len=0, big_threshold=0, waves_per_simd=0,
+             no_hot_help=False):
+    o = MsmOpts()
+    o.window_bits = window_bits
+    if windows is not None:
+        o.window_begin, o.window_end = windows
+    o.limb_bits = limb_bits
+    o.split_log_plus1 = 0 if split_log is None else split_log + 1
+    o.slice_len = slice_len
+    o.big_threshold = big_threshold
+    o.waves_per_simd = waves_per_simd
+    o.flags = MSM_FLAG_NO_HOT_HELP if no_hot_help else 0
+    return o
+
+
+def msm(bases, scalars, montgomery=False, window_bits=0, windows=None, stream=0, **tuning):
     """sum_i scalars[i] * bases[i] -> Jacobian (X, Y, Z) as uint64[3 * limbs].
 
-    scalars: numpy uint64 [n, 4] (host) or a torch uint64/int64 tensor on the GPU (device path)."""
+    scalars: numpy uint64 [n, 4] (host) or a torch uint64/int64 tensor on the GPU (device path).
+    tuning: the remaining zk_msm_opts fields (limb_bits, split_log, slice_len, big_threshold, waves_per_simd, no_hot_help)."""
     lib = load()
     nl = lib.zk_curve_base_limbs64(bases.curve)
     out = np.zeros(3 * nl, dtype=np.uint64)
-    opts = MsmOpts(window_bits, 0, 0, 0)
-    if windows is not None:
-        opts.window_begin, opts.window_end = windows
+    opts = msm_opts(window_bits, windows, **tuning)
     if isinstance(scalars, np.ndarray):
         sc = _np64(scalars)
         n = int(sc.shape[0])
@@ -240,10 +310,63 @@ def msm(bases, scalars, montgomery=False, window_bits=0, windows=None, stream=0)
     return out
 
 
+class MsmTicket:
+    """an MSM in flight (zk_msm_submit); .collect() waits for it and returns the Jacobian sum"""
+
+    def __init__(self, ticket, nl, keep):
+        self.ticket, self._nl, self._keep = ticket, nl, keep
+
+    def collect(self):
+        out = np.zeros(3 * self._nl, dtype=np.uint64)
+        _check(load().zk_msm_collect(self.ticket, _ptr(out)), "zk_msm_collect")
+        self._keep = None
+        return out
+
+
+def msm_submit(bases, d_scalars, montgomery=False, window_bits=0, windows=None, stream=0, **tuning):
+    """enqueue one MSM over device-resident scalars without synchronising; collect the ticket later"""
+    lib = load()
+    opts = msm_opts(window_bits, windows, **tuning)
+    t = ctypes.c_uint64(0)
+    _check(lib.zk_msm_submit(bases.curve, bases.handle, _ptr(d_scalars), int(d_scalars.shape[0]), int(montgomery), ctypes.byref(opts),
+                             ctypes.c_void_p(stream), ctypes.byref(t)), "zk_msm_submit")
+    return MsmTicket(t.value, lib.zk_curve_base_limbs64(bases.curve), d_scalars)
+
+
+def msm_batch(bases, d_scalars, montgomery=False, window_bits=0, windows=None, stream=0, **tuning):
+    """count MSMs over the same bases: d_scalars is a device buffer [count, n, 4]; returns [count, 3 * limbs]"""
+    lib = load()
+    count, n = int(d_scalars.shape[0]), int(d_scalars.shape[1])
+    nl = lib.zk_curve_base_limbs64(bases.curve)
+    out = np.zeros((count, 3 * nl), dtype=np.uint64)
+    opts = msm_opts(window_bits, windows, **tuning)
+    _check(lib.zk_msm_batch_device(bases.curve, bases.handle, _ptr(d_scalars), n, count, n, int(montgomery), ctypes.byref(opts),
+                                   _ptr(out), ctypes.c_void_p(stream)), "zk_msm_batch_device")
+    return out
+
+
 def msm_last_profile():
     p = MsmProfile()
     _check(load().zk_msm_last_profile(ctypes.byref(p)), "zk_msm_last_profile")
     return {k: getattr(p, k) for k, _ in MsmProfile._fields_}
+
+
+def msm_profile_totals(reset=True):
+    """sums over every MSM collected since the last reset (batches, MSMs in flight)"""
+    t = MsmTotals()
+    _check(load().zk_msm_profile_totals(ctypes.byref(t), int(reset)), "zk_msm_profile_totals")
+    return {k: getattr(t, k) for k, _ in MsmTotals._fields_}
+
+
+def ntt_profile_enable(on=True):
+    _check(load().zk_ntt_profile_enable(int(on)), "zk_ntt_profile_enable")
+
+
+def ntt_profile_read():
+    """waits for the bracketed ntt_pass_kernel launches since the last read; sums and resets"""
+    t = NttTotals()
+    _check(load().zk_ntt_profile_read(ctypes.byref(t)), "zk_ntt_profile_read")
+    return {k: getattr(t, k) for k, _ in NttTotals._fields_}
 
 
 def ntt(field, a, omega, scale_by_n_inv=False, stream=0, coset_pre=None, coset_post=None, device=False, in_log=None):
@@ -305,6 +428,11 @@ VEC_OPS = {"mul": 0, "sub": 1, "add": 2, "scale": 3, "into_repr": 4, "from_repr"
 def vec_op(field, op, a, b=None, c=None, scalar=None, stream=0):
     """Pointwise kernels on device buffers (torch tensors, or numpy arrays under the test emulator)."""
     n = int(a.shape[0])
+    if op == "scale_periodic":      # a[i] *= b[i mod len(b)], b a small host table
+        tbl = _np64(b)
+        _check(load().zk_vec_scale_periodic_device(field_id(field), _ptr(a), n, _ptr(tbl), int(tbl.shape[0]), ctypes.c_void_p(stream)),
+               "zk_vec_scale_periodic_device")
+        return a
     sp = _ptr(_np64(scalar)) if scalar is not None else None
     _check(load().zk_vec_op_device(field_id(field), VEC_OPS[op], _ptr(a), _ptr(b) if b is not None else None,
                                    _ptr(c) if c is not None else None, n, sp, ctypes.c_void_p(stream)), "zk_vec_op_device")

@@ -20,21 +20,23 @@ FIELDS = ["PallasFp", "PallasFq", "Bn254Fr", "Bls381Fr"]
 UNITS = [("zk_api.cc", None, "api")] + \
         [("zk_msm_inst.cc", "ZK_CURVE=" + c, "msm_" + c) for c in CURVES] + \
         [("zk_ntt_inst.cc", "ZK_FIELD=" + f, "ntt_" + f) for f in FIELDS]
-COMMON = ["zk_params.h", "zk_mul_asm.h", "zk_field.h", "zk_curve.h", "zk_rt.h", "zk_internal.h"]
-PER_SOURCE = {   # headers only this kind of unit includes: an NTT edit does not rebuild the (slow) curve units
-    "zk_api.cc": [],
-    "zk_msm_inst.cc": ["zk_msm.inl", "zk_msm_kernels.h", "zk_host64.h"],
-    "zk_ntt_inst.cc": ["zk_ntt.inl", "zk_ntt_kernels.h"],
-}
 
 
-def _deps(src=None):
-    names = set(COMMON)
-    for k, v in PER_SOURCE.items():
-        if src is None or k == src:
-            names.update(v)
-            names.add(k)
-    return [os.path.join(CSRC, f) for f in sorted(names)] + [os.path.join(ROOT, "include", "zkcp_amd.h")]
+def _all_sources():
+    """every header / source under csrc/ plus the public header: the conservative dependency set (used for the library
+    as a whole, and for an object whose compiler-written .d file does not exist yet)"""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inl", ".cc"))) + \
+        [os.path.join(ROOT, "include", "zkcp_amd.h")]
+
+
+def _deps(obj=None):
+    """dependencies of one object = what the compiler recorded the last time it built it (-MMD -MF obj.d): an edit to
+    the lazy-limb bucket arithmetic rebuilds the curve units, an NTT edit does not."""
+    if obj is not None and os.path.exists(obj + ".d"):
+        txt = open(obj + ".d").read().replace("\\\n", " ")
+        names = txt.split(":", 1)[1].split() if ":" in txt else []
+        return [n for n in names if not n.startswith("/opt/") and not n.startswith("/usr/")]
+    return _all_sources()
 
 
 def _newer(target, deps):
@@ -67,8 +69,8 @@ def _compile_all(base_cmd, objdir, extra_deps, verbose, jobs):
     for src, define, tag in UNITS:
         obj = os.path.join(objdir, tag + ".o")
         objs.append(obj)
-        if _newer(obj, _deps(src) + extra_deps):
-            cmd = base_cmd + (["-D" + define] if define else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if _newer(obj, _deps(obj) + extra_deps):
+            cmd = base_cmd + (["-D" + define] if define else []) + ["-MMD", "-MF", obj + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
             todo.append(cmd)
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
         list(ex.map(lambda c: _run(c, verbose), todo))

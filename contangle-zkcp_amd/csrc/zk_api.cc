@@ -1,8 +1,12 @@
-// C ABI implementation (include/zkcp_amd.h): argument checks, dispatch over curve / field and the
-// host-side helpers.  The launch sequences live in zk_msm.inl / zk_ntt.inl (one TU per curve /
-// field).  Compiled with `hipcc -x hip --offload-arch=gfx950` into libzkcp_amd.so.  (The CPU test
-// tier compiles the same files against tests/emu/emu_hip.h; see zk_rt.h.)
+// C ABI implementation (include/zkcp_amd.h): argument checks, dispatch over curve / field / device, the MSM job pool
+// (submit -> collect) and the host-side helpers.  The launch sequences live in zk_msm.inl / zk_ntt.inl (one TU per
+// curve / field).  Compiled with `hipcc -x hip --offload-arch=gfx950` into libzkcp_amd.so.  (The CPU test tier
+// compiles the same files against tests/emu/emu_hip.h; see zk_rt.h.)
 #include "zk_internal.h"
+#include "zk_msm_decl.h"
+#include "zk_ntt_decl.h"
+
+#include <thread>
 
 using namespace zk;
 
@@ -10,16 +14,39 @@ namespace zk {
 Ctx g;
 int msm_pick_c(uint64_t n, int requested) {
     if (requested > 0) return requested < 2 ? 2 : (requested > 16 ? 16 : requested);  // digits are stored as u16 codes
-    if (const char* e = getenv("ZK_MSM_C")) {
-        int v = atoi(e);
-        if (v >= 2 && v <= 16) return v;
-    }
     int l = 0;
     while ((1ull << l) < n) l++;
     int c = l - 4;  // ~2^5 points per bucket per window
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     return c;
+}
+
+// the scratch set of a caller stream: found by stream, created on first use, least-recently-used one recycled (after its
+// stream has drained) beyond ZK_MAX_STREAM_SCRATCH streams.  Called with dc.mu held.
+int stream_scratch(DeviceCtx& dc, hipStream_t st, StreamScratch** out) {
+    for (auto& s : dc.scratch)
+        if (s->stream == st) {
+            s->stamp = ++dc.scratch_stamp;
+            *out = s.get();
+            return ZK_OK;
+        }
+    if ((int)dc.scratch.size() < ZK_MAX_STREAM_SCRATCH) {
+        dc.scratch.emplace_back(new StreamScratch());
+        StreamScratch* s = dc.scratch.back().get();
+        s->stream = st;
+        s->stamp = ++dc.scratch_stamp;
+        *out = s;
+        return ZK_OK;
+    }
+    StreamScratch* victim = dc.scratch[0].get();
+    for (auto& s : dc.scratch)
+        if (s->stamp < victim->stamp) victim = s.get();
+    HIP_TRY(hipStreamSynchronize(victim->stream));   // its last user may still be running
+    victim->stream = st;
+    victim->stamp = ++dc.scratch_stamp;
+    *out = victim;
+    return ZK_OK;
 }
 }  // namespace zk
 
@@ -36,6 +63,325 @@ void jac_to_xyzz(XYZZ<C>& r, const Jacobian<C>& j) {
     fe_mul(r.zzz, r.zz, j.z);
 }
 
+int point_add_host(zk_curve_t c, const void* ja, const void* jb, void* jout) {
+    CURVE_SWITCH(c, {
+        Jacobian<C> a, b, r;
+        memcpy(&a, ja, 3 * 4 * coord_words<C>());
+        memcpy(&b, jb, 3 * 4 * coord_words<C>());
+        XYZZ<C> xa, xb;
+        jac_to_xyzz(xa, a);
+        jac_to_xyzz(xb, b);
+        xyzz_add(xa, xb);
+        xyzz_to_jacobian(r, xa);
+        memcpy(jout, &r, 3 * 4 * coord_words<C>());
+    });
+    return ZK_OK;
+}
+
+MsmTuning tuning_from(const zk_msm_opts* o) {
+    MsmTuning t;
+    if (!o) return t;
+    t.window_bits = o->window_bits;
+    t.w0 = o->window_begin;
+    t.w1 = o->window_end;
+    t.limb_bits = o->limb_bits;
+    t.split_log = o->split_log_plus1 > 0 ? o->split_log_plus1 - 1 : -1;
+    t.slice_len = o->slice_len > 0 ? (uint32_t)o->slice_len : 0;
+    t.big_thresh = o->big_threshold > 0 ? (uint32_t)o->big_threshold : 0;
+    t.waves = o->waves_per_simd;
+    t.no_hot_help = (o->flags & ZK_MSM_FLAG_NO_HOT_HELP) != 0;
+    return t;
+}
+
+void free_job(MsmJob& j) {
+    for (DevBuf* b : {&j.scalars_in, &j.hot, &j.counts, &j.digits, &j.blockcnt, &j.stage_idx, &j.stage_low, &j.queue, &j.seg_out, &j.subacc, &j.sorted,
+                      &j.buckets, &j.part_a, &j.part_b})
+        ws_free(*b);
+    if (j.host_partials) hipHostFree(j.host_partials);
+    j.host_partials = nullptr;
+    j.host_cap = 0;
+    if (j.have_events) {
+        for (auto& e : j.ev) hipEventDestroy(e);
+        j.have_events = false;
+    }
+    j.busy = false;
+}
+
+void free_device(DeviceCtx& dc) {
+    hipSetDevice(dc.device);
+    hipDeviceSynchronize();
+    for (auto& kv : dc.tw) hipFree(kv.second.dev);
+    dc.tw.clear();
+    dc.tw_bytes = 0;
+    ws_free(dc.pow_tbl);
+    ws_free(dc.scratch_in);
+    for (auto& s : dc.scratch) {
+        ws_free(s->ntt_tmp);
+        ws_free(s->fb_table);
+        ws_free(s->fb_tmp);
+    }
+    dc.scratch.clear();
+    for (auto& j : dc.jobs) free_job(j);
+    for (auto& e : dc.ntt_ev_pool) hipEventDestroy(e);
+    dc.ntt_ev_pool.clear();
+    dc.ntt_ev_used = 0;
+    for (auto& s : dc.side)
+        if (s) {
+            hipStreamDestroy(s);
+            s = nullptr;
+        }
+    if (dc.own) hipStreamDestroy(dc.own);
+    dc.own = nullptr;
+    if (dc.fork_ev) hipEventDestroy(dc.fork_ev);
+    dc.fork_ev = nullptr;
+    for (auto& e : dc.join_ev)
+        if (e) {
+            hipEventDestroy(e);
+            e = nullptr;
+        }
+}
+
+// the device that owns a device pointer; the home device when the runtime cannot tell (or under the emulator)
+DeviceCtx& device_of(const void* p) {
+    if (g.devs.size() > 1 && p) {
+#if !defined(ZK_EMU)
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) == hipSuccess) {
+            for (auto& d : g.devs)
+                if (d->device == attr.device) return *d;
+        } else {
+            (void)hipGetLastError();
+        }
+#endif
+    }
+    return *g.devs[0];
+}
+
+int ensure_lib_streams(DeviceCtx& dc) {
+    if (!dc.side[0]) {
+        for (auto& s : dc.side) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&dc.own, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&dc.fork_ev, hipEventDisableTiming));
+        for (auto& e : dc.join_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    return ZK_OK;
+}
+
+// take a free job slot of the device (dc.mu held).  All busy -> ZK_ERR_BUSY: the caller must collect first.
+int job_acquire(DeviceCtx& dc, MsmJob** out) {
+    for (auto& j : dc.jobs)
+        if (!j.busy) {
+            j.dc = &dc;
+            j.busy = true;
+            *out = &j;
+            return ZK_OK;
+        }
+    return ZK_ERR_BUSY;
+}
+
+// where the scalars of a submission are
+enum ScalarSrc { SRC_LOCAL = 0, SRC_HOST = 1, SRC_PEER = 2 };
+
+// enqueue one MSM on device dc / stream st (dc.mu held, thread bound to dc.device).  Scalars that are not already in this
+// device's memory are staged into a buffer the JOB owns, so MSMs in flight never share a staging area.
+int submit_on(DeviceCtx& dc, zk_curve_t c, const BasesEntry& be, const void* scalars, ScalarSrc kind, int peer_device, uint64_t n, int mont,
+              const MsmTuning& tu, hipStream_t st, MsmJob** out) {
+    MsmJob* job = nullptr;
+    ZK_TRY(job_acquire(dc, &job));
+    job->stream = st;
+    job->curve = (int)c;
+    int status = ZK_OK;
+    const void* d_scalars = scalars;
+    auto stage = [&]() -> int {
+        if (kind == SRC_LOCAL || n == 0) return ZK_OK;
+        ZK_TRY(ws_get(job->scalars_in, 32 * n));
+        d_scalars = job->scalars_in.p;
+        if (kind == SRC_HOST) {
+            HIP_TRY(hipMemcpyAsync(job->scalars_in.p, scalars, 32 * n, hipMemcpyHostToDevice, st));
+        } else {
+#if defined(ZK_EMU)
+            HIP_TRY(hipMemcpyAsync(job->scalars_in.p, scalars, 32 * n, hipMemcpyDeviceToDevice, st));
+#else
+            HIP_TRY(hipMemcpyPeerAsync(job->scalars_in.p, dc.device, scalars, peer_device, 32 * n, st));
+#endif
+        }
+        return ZK_OK;
+    };
+    status = stage();
+    (void)peer_device;
+    const BasesCopy& bc = be.per_dev[dc.index];
+    if (status == ZK_OK) {
+        status = ZK_ERR_INVALID_ARG;
+        switch (c) {
+            case ZK_PALLAS: status = msm_enqueue<Pallas>(*job, bc, (const Fe<Pallas::Fr>*)d_scalars, n, mont, tu); break;
+            case ZK_VESTA: status = msm_enqueue<Vesta>(*job, bc, (const Fe<Vesta::Fr>*)d_scalars, n, mont, tu); break;
+            case ZK_BN254_G1: status = msm_enqueue<Bn254G1>(*job, bc, (const Fe<Bn254G1::Fr>*)d_scalars, n, mont, tu); break;
+            case ZK_BLS12_381_G1: status = msm_enqueue<Bls381G1>(*job, bc, (const Fe<Bls381G1::Fr>*)d_scalars, n, mont, tu); break;
+            case ZK_BN254_G2: status = msm_enqueue<Bn254G2>(*job, bc, (const Fe<Bn254G2::Fr>*)d_scalars, n, mont, tu); break;
+            case ZK_BLS12_381_G2: status = msm_enqueue<Bls381G2>(*job, bc, (const Fe<Bls381G2::Fr>*)d_scalars, n, mont, tu); break;
+            default: break;
+        }
+    }
+    if (status != ZK_OK) {
+        job->busy = false;
+        return status;
+    }
+    *out = job;
+    return ZK_OK;
+}
+
+int collect_job(MsmJob& job, void* out) {
+    hipSetDevice(job.dc->device);
+    const int status = job.finish(job, out);
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.prof = job.prof;
+        if (!job.empty) {
+            g.totals.msms++;
+            g.totals.accumulate_kernel_ms += job.prof.accumulate_kernel_ms;
+            g.totals.accumulate_ms += job.prof.accumulate_ms;
+            g.totals.sort_ms += job.prof.digits_ms + job.prof.hist_ms + job.prof.scatter_ms;
+            g.totals.reduce_ms += job.prof.reduce_ms;
+            g.totals.host_tail_ms += job.prof.host_tail_ms;
+            g.totals.device_ms += job.prof.total_ms - job.prof.host_tail_ms;
+            g.totals.algorithmic_bytes += job.alg_bytes;
+        }
+    }
+    std::lock_guard<std::mutex> lk(job.dc->mu);
+    job.busy = false;
+    return status;
+}
+
+int find_bases(uint64_t handle, zk_curve_t c, uint64_t n, const BasesEntry** out) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    ZK_TRY(require_init());
+    auto it = g.bases.find(handle);
+    if (it == g.bases.end()) return ZK_ERR_BAD_HANDLE;
+    if (it->second.curve != (int)c || n > it->second.n) return ZK_ERR_INVALID_ARG;
+    *out = &it->second;   // entries are only erased by zk_bases_free, which the caller must not race with a running MSM
+    return ZK_OK;
+}
+
+// One MSM over all devices of the process: device d sums windows [W d / G, W (d + 1) / G) from its own resident copy of
+// the bases; the Jacobian partial sums are added on the host (EC addition is not an RCCL reduction; the partial is 96 -
+// 288 bytes and is already on the host after the job's tail).  `src` is where the scalars are: a host pointer (src_dc ==
+// nullptr; every device copies them over its own PCIe link) or a device pointer owned by src_dc (peers copy over xGMI).
+int msm_fanout(zk_curve_t c, const BasesEntry& be, const void* src, DeviceCtx* src_dc, hipStream_t src_stream, uint64_t n, int mont,
+               const MsmTuning& tu_in, void* out) {
+    const int G = (int)g.devs.size();
+    int nwin = 0;
+    CURVE_SWITCH(c, nwin = msm_windows<C>(msm_pick_c(n, tu_in.window_bits)));
+    const size_t pbytes = (size_t)3 * 4 * [&]() -> size_t {
+        size_t w = 0;
+        switch (c) {
+            case ZK_PALLAS: w = coord_words<Pallas>(); break;
+            case ZK_VESTA: w = coord_words<Vesta>(); break;
+            case ZK_BN254_G1: w = coord_words<Bn254G1>(); break;
+            case ZK_BLS12_381_G1: w = coord_words<Bls381G1>(); break;
+            case ZK_BN254_G2: w = coord_words<Bn254G2>(); break;
+            default: w = coord_words<Bls381G2>(); break;
+        }
+        return w;
+    }();
+    std::vector<std::vector<unsigned char>> parts(G, std::vector<unsigned char>(pbytes));
+    std::vector<int> status(G, ZK_OK);
+    hipEvent_t ready = nullptr;
+    if (src_dc) {   // peers must not read the scalars before the caller's stream has produced them
+        hipSetDevice(src_dc->device);
+        std::lock_guard<std::mutex> lk(src_dc->mu);
+        ZK_TRY(ensure_lib_streams(*src_dc));
+        ready = src_dc->fork_ev;
+        HIP_TRY(hipEventRecord(ready, src_stream));
+    }
+    auto work = [&](int d) {
+        DeviceCtx& dc = *g.devs[d];
+        MsmTuning tu = tu_in;
+        tu.w0 = nwin * d / G;
+        tu.w1 = nwin * (d + 1) / G;
+        MsmJob* job = nullptr;
+        int st_ = ZK_OK;
+        auto run = [&]() -> int {
+            ZK_TRY(bind_device(dc));
+            std::lock_guard<std::mutex> lk(dc.mu);
+            if (tu.w0 == tu.w1) {   // more devices than windows: this one contributes the identity
+                tu.w0 = tu.w1 = 0;
+                return submit_on(dc, c, be, nullptr, SRC_LOCAL, 0, 0, mont, tu, nullptr, &job);
+            }
+            ZK_TRY(ensure_lib_streams(dc));
+            if (!src_dc) return submit_on(dc, c, be, src, SRC_HOST, 0, n, mont, tu, dc.own, &job);
+            if (&dc == src_dc) return submit_on(dc, c, be, src, SRC_LOCAL, 0, n, mont, tu, src_stream, &job);
+            HIP_TRY(hipStreamWaitEvent(dc.own, ready, 0));
+            return submit_on(dc, c, be, src, SRC_PEER, src_dc->device, n, mont, tu, dc.own, &job);
+        };
+        st_ = run();
+        if (st_ == ZK_OK) st_ = collect_job(*job, parts[d].data());
+        status[d] = st_;
+    };
+    std::vector<std::thread> th;
+    for (int d = 1; d < G; d++) th.emplace_back(work, d);
+    work(0);
+    for (auto& t : th) t.join();
+    for (int d = 0; d < G; d++) ZK_TRY(status[d]);
+    memcpy(out, parts[0].data(), pbytes);
+    for (int d = 1; d < G; d++) ZK_TRY(point_add_host(c, out, parts[d].data(), out));
+    hipSetDevice(g.devs[0]->device);
+    return ZK_OK;
+}
+
+bool whole_msm(const MsmTuning& tu) { return tu.w0 == 0 && tu.w1 == 0; }
+
+int init_devices_locked(int n, const int* ids) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZK_ERR_NO_DEVICE;
+    if (n <= 0 || n > ndev || !ids) return ZK_ERR_INVALID_ARG;
+    for (int i = 0; i < n; i++) {
+        if (ids[i] < 0 || ids[i] >= ndev) return ZK_ERR_INVALID_ARG;
+        for (int j = 0; j < i; j++)
+            if (ids[j] == ids[i]) return ZK_ERR_INVALID_ARG;
+    }
+    if (g.inited) {
+        if ((int)g.devs.size() != n) return ZK_ERR_INVALID_ARG;
+        for (int i = 0; i < n; i++)
+            if (g.devs[i]->device != ids[i]) return ZK_ERR_INVALID_ARG;
+        return ZK_OK;
+    }
+    std::vector<std::unique_ptr<DeviceCtx>> devs;
+    for (int i = 0; i < n; i++) {
+        if (hipSetDevice(ids[i]) != hipSuccess) return ZK_ERR_NO_DEVICE;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ids[i]) != hipSuccess) return ZK_ERR_NO_DEVICE;
+        std::unique_ptr<DeviceCtx> dc(new DeviceCtx());
+        dc->device = ids[i];
+        dc->index = i;
+        dc->num_cus = prop.multiProcessorCount;
+        if (i == 0) {
+#if defined(ZK_EMU)
+            snprintf(g.info, sizeof g.info, "emu %s x%d", prop.name, n);
+#else
+            snprintf(g.info, sizeof g.info, "hip %s %s cu=%d x%d", prop.gcnArchName, prop.name, prop.multiProcessorCount, n);
+#endif
+        }
+        devs.push_back(std::move(dc));
+    }
+#if !defined(ZK_EMU)
+    for (int i = 0; i < n; i++)   // peers copy scalars to each other over xGMI
+        for (int j = 0; j < n; j++)
+            if (i != j) {
+                hipSetDevice(ids[i]);
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, ids[i], ids[j]) == hipSuccess && can) {
+                    if (hipDeviceEnablePeerAccess(ids[j], 0) != hipSuccess) (void)hipGetLastError();   // already enabled is fine
+                }
+            }
+#endif
+    hipSetDevice(ids[0]);
+    g.devs = std::move(devs);
+    memset(&g.ntt_opts, 0, sizeof g.ntt_opts);
+    memset(&g.totals, 0, sizeof g.totals);
+    g.ntt_profile = false;
+    g.inited = true;
+    return ZK_OK;
+}
 }  // namespace
 
 // ====================================================================== exported C ABI
@@ -52,52 +398,40 @@ API const char* zk_strerror(int s) {
         case ZK_ERR_HIP: return "HIP runtime error";
         case ZK_ERR_OOM: return "out of device memory";
         case ZK_ERR_UNSUPPORTED: return "unsupported size or curve";
-        case ZK_ERR_BAD_HANDLE: return "unknown bases handle";
+        case ZK_ERR_BAD_HANDLE: return "unknown bases handle or MSM ticket";
+        case ZK_ERR_BUSY: return "too many MSMs in flight on this device: collect one first";
         default: return "unknown status";
     }
 }
 
 API int zk_init(int device_id) {
     std::lock_guard<std::mutex> lk(g.mu);
-    if (g.inited) return g.device == device_id ? ZK_OK : ZK_ERR_INVALID_ARG;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZK_ERR_NO_DEVICE;
-    if (device_id < 0 || device_id >= ndev) return ZK_ERR_INVALID_ARG;
-    if (hipSetDevice(device_id) != hipSuccess) return ZK_ERR_NO_DEVICE;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return ZK_ERR_NO_DEVICE;
-#if defined(ZK_EMU)
-    snprintf(g.info, sizeof g.info, "emu %s", prop.name);
-#else
-    snprintf(g.info, sizeof g.info, "hip %s %s cu=%d", prop.gcnArchName, prop.name, prop.multiProcessorCount);
-#endif
-    g.num_cus = prop.multiProcessorCount;
-    g.device = device_id;
-    g.inited = true;
-    return ZK_OK;
+    return init_devices_locked(1, &device_id);
+}
+API int zk_init_devices(int n_devices, const int* device_ids) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    return init_devices_locked(n_devices, device_ids);
+}
+API int zk_device_count(void) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    return g.inited ? (int)g.devs.size() : 0;
 }
 
 API int zk_shutdown(void) {
     std::lock_guard<std::mutex> lk(g.mu);
     if (!g.inited) return ZK_OK;
-    hipDeviceSynchronize();
-    for (auto& kv : g.bases) {
-        if (kv.second.owned) hipFree(kv.second.dev);
-        if (kv.second.dev29) hipFree(kv.second.dev29);
-    }
+    for (auto& kv : g.bases)
+        for (size_t d = 0; d < kv.second.per_dev.size(); d++) {
+            hipSetDevice(g.devs[d]->device);
+            hipDeviceSynchronize();
+            if (kv.second.per_dev[d].owned) hipFree(kv.second.per_dev[d].dev);
+            if (kv.second.per_dev[d].dev29) hipFree(kv.second.per_dev[d].dev29);
+        }
     g.bases.clear();
-    for (auto& kv : g.tw) hipFree(kv.second.dev);
-    g.tw.clear();
-    g.tw_bytes = 0;
-    for (DevBuf* b : {&g.ntt_tmp, &g.pow_tbl, &g.fb_table, &g.fb_tmp, &g.msm_hot, &g.msm_counts, &g.msm_digits, &g.msm_blockcnt, &g.msm_stage_idx, &g.msm_stage_low, &g.msm_queue, &g.msm_seg_out, &g.msm_subacc, &g.msm_sorted, &g.msm_buckets, &g.msm_part_a, &g.msm_part_b,
-                      &g.scratch_in, &g.scratch_out})
-        ws_free(*b);
-    if (g.have_events) {
-        for (auto& e : g.ev) hipEventDestroy(e);
-        g.have_events = false;
-    }
+    g.tickets.clear();
+    for (auto& dc : g.devs) free_device(*dc);
+    g.devs.clear();
     g.inited = false;
-    g.device = -1;
     return ZK_OK;
 }
 
@@ -137,76 +471,214 @@ API int zk_msm_window_count(zk_curve_t c, uint64_t n, int window_bits) {
     return ZK_ERR_INVALID_ARG;
 }
 
+// bases: one resident copy per device of the process.  `src_dev` >= 0: `src` is a device pointer on that device index
+// (adopted there without a copy, copied to the peers); -1: `src` is host memory.
+static int bases_install(zk_curve_t c, const void* src, int src_dev, uint64_t n, uint64_t* handle_out) {
+    size_t esz = 0;
+    CURVE_SWITCH(c, esz = sizeof(Affine<C>));
+    BasesEntry be;
+    be.curve = (int)c;
+    be.n = n;
+    be.per_dev.resize(g.devs.size());
+    auto cleanup = [&]() {
+        for (size_t d = 0; d < be.per_dev.size(); d++) {
+            hipSetDevice(g.devs[d]->device);
+            if (be.per_dev[d].owned && be.per_dev[d].dev) hipFree(be.per_dev[d].dev);
+            if (be.per_dev[d].dev29) hipFree(be.per_dev[d].dev29);
+        }
+        hipSetDevice(g.devs[0]->device);
+    };
+    for (size_t d = 0; d < g.devs.size(); d++) {
+        DeviceCtx& dc = *g.devs[d];
+        BasesCopy& bc = be.per_dev[d];
+        int st = bind_device(dc);
+        if (st == ZK_OK) {
+            if ((int)d == src_dev) {
+                bc.dev = const_cast<void*>(src);
+                bc.owned = false;
+            } else {
+                hipError_t e = hipMalloc(&bc.dev, esz * (n ? n : 1));
+                if (e != hipSuccess) {
+                    bc.dev = nullptr;
+                    st = e == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP;
+                } else {
+                    bc.owned = true;
+                    if (n) {
+                        if (src_dev < 0)
+                            e = hipMemcpy(bc.dev, src, esz * n, hipMemcpyHostToDevice);
+                        else
+#if defined(ZK_EMU)
+                            e = hipMemcpy(bc.dev, src, esz * n, hipMemcpyDeviceToDevice);
+#else
+                            e = hipMemcpyPeer(bc.dev, dc.device, src, g.devs[src_dev]->device, esz * n);
+#endif
+                        if (e != hipSuccess) st = ZK_ERR_HIP;
+                    }
+                }
+            }
+        }
+        if (st == ZK_OK) CURVE_SWITCH(c, st = bases_prepare_run<C>(bc, n));
+        if (st != ZK_OK) {
+            cleanup();
+            return st;
+        }
+    }
+    hipSetDevice(g.devs[0]->device);
+    const uint64_t h = g.next_handle++;
+    g.bases[h] = std::move(be);
+    *handle_out = h;
+    return ZK_OK;
+}
+
 API int zk_bases_upload(zk_curve_t c, const void* host, uint64_t n, uint64_t* handle_out) {
     std::lock_guard<std::mutex> lk(g.mu);
     ZK_TRY(require_init());
     if (!handle_out || (n && !host)) return ZK_ERR_INVALID_ARG;
-    size_t esz = 0;
-    CURVE_SWITCH(c, esz = sizeof(Affine<C>));
-    void* dev = nullptr;
-    HIP_TRY(hipMalloc(&dev, esz * (n ? n : 1)));
-    if (n) HIP_TRY(hipMemcpy(dev, host, esz * n, hipMemcpyHostToDevice));
-    const uint64_t h = g.next_handle++;
-    BasesEntry be{(int)c, dev, n, true, nullptr};
-    CURVE_SWITCH(c, {
-        int st = bases_prepare_run<C>(be);
-        if (st != ZK_OK) {
-            hipFree(dev);
-            return st;
-        }
-    });
-    g.bases[h] = be;
-    *handle_out = h;
-    return ZK_OK;
+    return bases_install(c, host, -1, n, handle_out);
 }
 API int zk_bases_adopt_device(zk_curve_t c, const void* dev, uint64_t n, uint64_t* handle_out) {
     std::lock_guard<std::mutex> lk(g.mu);
     ZK_TRY(require_init());
     if (!handle_out || !dev || !aligned16(dev)) return ZK_ERR_INVALID_ARG;
-    BasesEntry be{(int)c, const_cast<void*>(dev), n, false, nullptr};
-    CURVE_SWITCH(c, ZK_TRY(bases_prepare_run<C>(be)));
-    const uint64_t h = g.next_handle++;
-    g.bases[h] = be;
-    *handle_out = h;
-    return ZK_OK;
+    return bases_install(c, dev, device_of(dev).index, n, handle_out);
 }
 API int zk_bases_free(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g.mu);
     ZK_TRY(require_init());
     auto it = g.bases.find(handle);
     if (it == g.bases.end()) return ZK_ERR_BAD_HANDLE;
-    if (it->second.owned || it->second.dev29) hipDeviceSynchronize();
-    if (it->second.owned) hipFree(it->second.dev);
-    if (it->second.dev29) hipFree(it->second.dev29);
+    for (size_t d = 0; d < it->second.per_dev.size(); d++) {
+        BasesCopy& bc = it->second.per_dev[d];
+        hipSetDevice(g.devs[d]->device);
+        if (bc.owned || bc.dev29) hipDeviceSynchronize();
+        if (bc.owned) hipFree(bc.dev);
+        if (bc.dev29) hipFree(bc.dev29);
+    }
+    hipSetDevice(g.devs[0]->device);
     g.bases.erase(it);
     return ZK_OK;
 }
 
-static int msm_locked(zk_curve_t c, uint64_t handle, const void* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
-                      void* out, hipStream_t st) {
-    auto it = g.bases.find(handle);
-    if (it == g.bases.end()) return ZK_ERR_BAD_HANDLE;
-    if (it->second.curve != (int)c || n > it->second.n) return ZK_ERR_INVALID_ARG;
-    CURVE_SWITCH(c, return msm_run<C>(it->second, (const Fe<typename C::Fr>*)d_scalars, n, mont, opts, out, st));
-    return ZK_ERR_INVALID_ARG;
+API int zk_msm_submit(zk_curve_t c, uint64_t handle, const void* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts, void* stream,
+                      uint64_t* ticket_out) {
+    if (!ticket_out || (n && (!d_scalars || !aligned16(d_scalars)))) return ZK_ERR_INVALID_ARG;
+    const BasesEntry* be = nullptr;
+    ZK_TRY(find_bases(handle, c, n, &be));
+    DeviceCtx& dc = device_of(d_scalars);
+    ZK_TRY(bind_device(dc));
+    MsmJob* job = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(dc.mu);
+        ZK_TRY(submit_on(dc, c, *be, d_scalars, SRC_LOCAL, 0, n, mont ? 1 : 0, tuning_from(opts), (hipStream_t)stream, &job));
+    }
+    std::lock_guard<std::mutex> lk(g.mu);
+    job->ticket = g.next_ticket++;
+    g.tickets[job->ticket] = job;
+    *ticket_out = job->ticket;
+    return ZK_OK;
+}
+API int zk_msm_collect(uint64_t ticket, void* out) {
+    if (!out) return ZK_ERR_INVALID_ARG;
+    MsmJob* job = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        ZK_TRY(require_init());
+        auto it = g.tickets.find(ticket);
+        if (it == g.tickets.end()) return ZK_ERR_BAD_HANDLE;
+        job = it->second;
+        g.tickets.erase(it);
+    }
+    return collect_job(*job, out);
 }
 
 API int zk_msm_device(zk_curve_t c, uint64_t handle, const void* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
                       void* out, void* stream) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
     if (!out || (n && (!d_scalars || !aligned16(d_scalars)))) return ZK_ERR_INVALID_ARG;
-    return msm_locked(c, handle, d_scalars, n, mont, opts, out, (hipStream_t)stream);
+    const BasesEntry* be = nullptr;
+    ZK_TRY(find_bases(handle, c, n, &be));
+    const MsmTuning tu = tuning_from(opts);
+    DeviceCtx& dc = device_of(d_scalars);
+    if (g.devs.size() > 1 && whole_msm(tu) && n > 0) return msm_fanout(c, *be, d_scalars, &dc, (hipStream_t)stream, n, mont ? 1 : 0, tu, out);
+    ZK_TRY(bind_device(dc));
+    MsmJob* job = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(dc.mu);
+        ZK_TRY(submit_on(dc, c, *be, d_scalars, SRC_LOCAL, 0, n, mont ? 1 : 0, tu, (hipStream_t)stream, &job));
+    }
+    return collect_job(*job, out);
 }
 
 API int zk_msm(zk_curve_t c, uint64_t handle, const void* scalars_host, uint64_t n, int mont, const zk_msm_opts* opts,
                void* out) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
     if (!out || (n && !scalars_host)) return ZK_ERR_INVALID_ARG;
-    ZK_TRY(ws_get(g.scratch_in, 32 * (n ? n : 1)));
-    if (n) HIP_TRY(hipMemcpy(g.scratch_in.p, scalars_host, 32 * n, hipMemcpyHostToDevice));
-    return msm_locked(c, handle, g.scratch_in.p, n, mont, opts, out, (hipStream_t)0);
+    const BasesEntry* be = nullptr;
+    ZK_TRY(find_bases(handle, c, n, &be));
+    const MsmTuning tu = tuning_from(opts);
+    if (g.devs.size() > 1 && whole_msm(tu) && n > 0) return msm_fanout(c, *be, scalars_host, nullptr, nullptr, n, mont ? 1 : 0, tu, out);
+    DeviceCtx& dc = *g.devs[0];
+    ZK_TRY(bind_device(dc));
+    MsmJob* job = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(dc.mu);
+        ZK_TRY(submit_on(dc, c, *be, scalars_host, SRC_HOST, 0, n, mont ? 1 : 0, tu, (hipStream_t)0, &job));
+    }
+    return collect_job(*job, out);
+}
+
+API int zk_msm_batch_device(zk_curve_t c, uint64_t handle, const void* d_scalars, uint64_t n, uint32_t count, uint64_t stride_elems,
+                            int mont, const zk_msm_opts* opts, void* out, void* stream) {
+    if (count == 0) return ZK_OK;
+    if (!out || stride_elems < n || (n && (!d_scalars || !aligned16(d_scalars)))) return ZK_ERR_INVALID_ARG;
+    const BasesEntry* be = nullptr;
+    ZK_TRY(find_bases(handle, c, n, &be));
+    const MsmTuning tu = tuning_from(opts);
+    DeviceCtx& dc = device_of(d_scalars);
+    ZK_TRY(bind_device(dc));
+    size_t pbytes = 0;
+    CURVE_SWITCH(c, pbytes = (size_t)3 * 4 * coord_words<C>());
+    {
+        std::lock_guard<std::mutex> lk(dc.mu);
+        ZK_TRY(ensure_lib_streams(dc));
+        HIP_TRY(hipEventRecord(dc.fork_ev, (hipStream_t)stream));
+        for (auto& s : dc.side) HIP_TRY(hipStreamWaitEvent(s, dc.fork_ev, 0));
+    }
+    // MSM k runs on side stream k mod 2; at most ZK_MAX_JOBS - 1 in flight, collected in order
+    std::vector<MsmJob*> inflight;
+    uint32_t submitted = 0, collected = 0;
+    int status = ZK_OK;
+    while (collected < count && status == ZK_OK) {
+        while (submitted < count && inflight.size() < (size_t)ZK_MAX_JOBS - 1 && status == ZK_OK) {
+            MsmJob* job = nullptr;
+            std::lock_guard<std::mutex> lk(dc.mu);
+            status = submit_on(dc, c, *be, (const unsigned char*)d_scalars + (size_t)submitted * stride_elems * 32, SRC_LOCAL, 0, n, mont ? 1 : 0,
+                               tu, dc.side[submitted & 1], &job);
+            if (status == ZK_ERR_BUSY && !inflight.empty()) {   // other callers hold the remaining slots: drain ours first
+                status = ZK_OK;
+                break;
+            }
+            if (status == ZK_OK) {
+                inflight.push_back(job);
+                submitted++;
+            }
+        }
+        if (status != ZK_OK || inflight.empty()) break;
+        status = collect_job(*inflight.front(), (unsigned char*)out + (size_t)collected * pbytes);
+        inflight.erase(inflight.begin());
+        collected++;
+    }
+    for (MsmJob* j : inflight) {   // error path: release what is still in flight
+        std::vector<unsigned char> sink(pbytes);
+        collect_job(*j, sink.data());
+    }
+    if (status == ZK_OK && collected < count) status = ZK_ERR_BUSY;
+    {
+        std::lock_guard<std::mutex> lk(dc.mu);
+        for (int s = 0; s < 2; s++) {
+            HIP_TRY(hipEventRecord(dc.join_ev[s], dc.side[s]));
+            HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, dc.join_ev[s], 0));
+        }
+    }
+    return status;
 }
 
 API int zk_msm_last_profile(zk_msm_profile* out) {
@@ -216,53 +688,110 @@ API int zk_msm_last_profile(zk_msm_profile* out) {
     return ZK_OK;
 }
 
-API int zk_ntt_device(zk_field_t f, void* a, uint32_t log_n, const void* omega, int scale, void* stream) {
+API int zk_msm_profile_totals(zk_msm_totals* out, int reset) {
     std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
+    if (!out) return ZK_ERR_INVALID_ARG;
+    *out = g.totals;
+    if (reset) memset(&g.totals, 0, sizeof g.totals);
+    return ZK_OK;
+}
+
+API int zk_ntt_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.ntt_profile = on != 0;
+    return ZK_OK;
+}
+API int zk_ntt_profile_read(zk_ntt_totals* out) {
+    if (!out) return ZK_ERR_INVALID_ARG;
+    {
+        std::lock_guard<std::mutex> lk0(g.mu);
+        ZK_TRY(require_init());
+    }
+    memset(out, 0, sizeof *out);
+    for (auto& dcp : g.devs) {
+        DeviceCtx& dc = *dcp;
+        ZK_TRY(bind_device(dc));
+        std::lock_guard<std::mutex> lk(dc.mu);
+        for (size_t i = 0; i + 1 < dc.ntt_ev_used; i += 2) {
+            HIP_TRY(hipEventSynchronize(dc.ntt_ev_pool[i + 1]));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, dc.ntt_ev_pool[i], dc.ntt_ev_pool[i + 1]));
+            out->kernel_ms += ms;
+            out->launches++;
+        }
+        out->transforms += dc.ntt_transforms;
+        out->algorithmic_bytes += dc.ntt_alg_bytes;
+        dc.ntt_ev_used = 0;
+        dc.ntt_transforms = 0;
+        dc.ntt_alg_bytes = 0;
+    }
+    hipSetDevice(g.devs[0]->device);
+    return ZK_OK;
+}
+
+API int zk_ntt_configure(const zk_ntt_opts* opts) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (opts)
+        g.ntt_opts = *opts;
+    else
+        memset(&g.ntt_opts, 0, sizeof g.ntt_opts);
+    return ZK_OK;
+}
+
+// entry points on device buffers: bind the calling thread to the owner of `a`, serialise the enqueue on that device
+#define DEVICE_ENTRY(ptr)                       \
+    {                                           \
+        std::lock_guard<std::mutex> lk0(g.mu);  \
+        ZK_TRY(require_init());                 \
+    }                                           \
+    DeviceCtx& dc = device_of(ptr);             \
+    ZK_TRY(bind_device(dc));                    \
+    std::lock_guard<std::mutex> lk(dc.mu)
+
+API int zk_ntt_device(zk_field_t f, void* a, uint32_t log_n, const void* omega, int scale, void* stream) {
     if (!a || !omega || !aligned16(a)) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(a);
     FIELD_SWITCH(f, {
         Fe<F> w;
         host_load(w, omega);
-        return ntt_run<F>((int)f, (Fe<F>*)a, log_n, w, scale, (hipStream_t)stream);
+        return ntt_run<F>(dc, (int)f, (Fe<F>*)a, log_n, w, scale, (hipStream_t)stream);
     });
     return ZK_ERR_INVALID_ARG;
 }
 API int zk_ntt(zk_field_t f, void* a_host, uint32_t log_n, const void* omega, int scale) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
     if (!a_host || !omega || log_n > 30) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(nullptr);
     const size_t bytes = (size_t)32 << log_n;
-    ZK_TRY(ws_get(g.scratch_in, bytes));
-    HIP_TRY(hipMemcpy(g.scratch_in.p, a_host, bytes, hipMemcpyHostToDevice));
+    ZK_TRY(ws_get(dc.scratch_in, bytes));
+    HIP_TRY(hipMemcpy(dc.scratch_in.p, a_host, bytes, hipMemcpyHostToDevice));
     FIELD_SWITCH(f, {
         Fe<F> w;
         host_load(w, omega);
-        ZK_TRY(ntt_run<F>((int)f, (Fe<F>*)g.scratch_in.p, log_n, w, scale, (hipStream_t)0));
+        ZK_TRY(ntt_run<F>(dc, (int)f, (Fe<F>*)dc.scratch_in.p, log_n, w, scale, (hipStream_t)0));
     });
     HIP_TRY(hipStreamSynchronize((hipStream_t)0));
-    HIP_TRY(hipMemcpy(a_host, g.scratch_in.p, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(a_host, dc.scratch_in.p, bytes, hipMemcpyDeviceToHost));
     return ZK_OK;
 }
 API int zk_ntt_coset_device(zk_field_t f, void* a, uint32_t log_n, const void* omega, int scale, const void* g_pre,
                             const void* g_post, void* stream) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
     if (!a || !omega || !aligned16(a)) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(a);
     FIELD_SWITCH(f, {
         Fe<F> w, gp, gq;
         host_load(w, omega);
         if (g_pre) host_load(gp, g_pre);
         if (g_post) host_load(gq, g_post);
-        return ntt_run<F>((int)f, (Fe<F>*)a, log_n, w, scale, (hipStream_t)stream, g_pre ? &gp : nullptr, g_post ? &gq : nullptr);
+        return ntt_run<F>(dc, (int)f, (Fe<F>*)a, log_n, w, scale, (hipStream_t)stream, g_pre ? &gp : nullptr, g_post ? &gq : nullptr);
     });
     return ZK_ERR_INVALID_ARG;
 }
 API int zk_ntt_extend_device(zk_field_t f, void* a, uint32_t log_n, uint32_t log_in, const void* omega, int scale, const void* g_pre,
                              const void* g_post, void* stream) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
-    if (!a || !omega || !aligned16(a) || log_in > log_n) return ZK_ERR_INVALID_ARG;
+    if (!a || !omega || !aligned16(a) || log_in > log_n || log_n > 30) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(a);
     FIELD_SWITCH(f, {
+        if (log_n > (uint32_t)F::TWO_ADICITY) return ZK_ERR_INVALID_ARG;
         Fe<F> w, gp, gq;
         host_load(w, omega);
         if (g_pre) host_load(gp, g_pre);
@@ -270,43 +799,40 @@ API int zk_ntt_extend_device(zk_field_t f, void* a, uint32_t log_n, uint32_t log
         if (log_n > 0 && log_in == 0) {   // a single coefficient: in_log = 0 means "all" to the pass kernel, so pad explicitly
             HIP_TRY(hipMemsetAsync((Fe<F>*)a + 1, 0, (((size_t)1 << log_n) - 1) * sizeof(Fe<F>), (hipStream_t)stream));
         }
-        return ntt_run<F>((int)f, (Fe<F>*)a, log_n, w, scale, (hipStream_t)stream, g_pre ? &gp : nullptr, g_post ? &gq : nullptr, log_in);
+        return ntt_run<F>(dc, (int)f, (Fe<F>*)a, log_n, w, scale, (hipStream_t)stream, g_pre ? &gp : nullptr, g_post ? &gq : nullptr, log_in);
     });
     return ZK_ERR_INVALID_ARG;
 }
 API int zk_coset_mul_device(zk_field_t f, void* a, uint32_t log_n, const void* gm, void* stream) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
     if (!a || !gm || !aligned16(a)) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(a);
     FIELD_SWITCH(f, {
         Fe<F> w;
         host_load(w, gm);
-        return coset_run<F>((int)f, (Fe<F>*)a, log_n, w, (hipStream_t)stream);
+        return coset_run<F>(dc, (int)f, (Fe<F>*)a, log_n, w, (hipStream_t)stream);
     });
     return ZK_ERR_INVALID_ARG;
 }
 API int zk_coset_mul(zk_field_t f, void* a_host, uint32_t log_n, const void* gm) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
     if (!a_host || !gm || log_n > 30) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(nullptr);
     const size_t bytes = (size_t)32 << log_n;
-    ZK_TRY(ws_get(g.scratch_in, bytes));
-    HIP_TRY(hipMemcpy(g.scratch_in.p, a_host, bytes, hipMemcpyHostToDevice));
+    ZK_TRY(ws_get(dc.scratch_in, bytes));
+    HIP_TRY(hipMemcpy(dc.scratch_in.p, a_host, bytes, hipMemcpyHostToDevice));
     FIELD_SWITCH(f, {
         Fe<F> w;
         host_load(w, gm);
-        ZK_TRY(coset_run<F>((int)f, (Fe<F>*)g.scratch_in.p, log_n, w, (hipStream_t)0));
+        ZK_TRY(coset_run<F>(dc, (int)f, (Fe<F>*)dc.scratch_in.p, log_n, w, (hipStream_t)0));
     });
-    HIP_TRY(hipMemcpy(a_host, g.scratch_in.p, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(a_host, dc.scratch_in.p, bytes, hipMemcpyDeviceToHost));
     return ZK_OK;
 }
 
 API int zk_vec_op_device(zk_field_t f, int op, void* a, const void* b, const void* c, uint64_t n, const void* scalar, void* stream) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
     if (op < 0 || op > 6 || (n && (!a || !aligned16(a)))) return ZK_ERR_INVALID_ARG;
     const bool needs_b = op == 0 || op == 1 || op == 2 || op == 6, needs_c = op == 6, needs_s = op == 3 || op == 6;
     if (n && ((needs_b && (!b || !aligned16(b))) || (needs_c && (!c || !aligned16(c))) || (needs_s && !scalar))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(a);
     FIELD_SWITCH(f, {
         Fe<F> s;
         fe_one(s);
@@ -315,14 +841,24 @@ API int zk_vec_op_device(zk_field_t f, int op, void* a, const void* b, const voi
     });
     return ZK_ERR_INVALID_ARG;
 }
+API int zk_vec_scale_periodic_device(zk_field_t f, void* a, uint64_t n, const void* table_host, uint32_t m, void* stream) {
+    if ((n && (!a || !aligned16(a))) || !table_host) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(a);
+    FIELD_SWITCH(f, return scale_periodic_run<F>((Fe<F>*)a, n, (const Fe<F>*)table_host, m, (hipStream_t)stream));
+    return ZK_ERR_INVALID_ARG;
+}
 API int zk_groth16_witness_map_device(zk_field_t f, void* a, void* b, void* c, uint32_t log_m, void* stream) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
     if (!a || !b || !c || !aligned16(a) || !aligned16(b) || !aligned16(c)) return ZK_ERR_INVALID_ARG;
-    FIELD_SWITCH(f, return witness_map_run<F>((int)f, (Fe<F>*)a, (Fe<F>*)b, (Fe<F>*)c, log_m, (hipStream_t)stream));
+    DEVICE_ENTRY(a);
+    FIELD_SWITCH(f, return witness_map_run<F>(dc, (int)f, (Fe<F>*)a, (Fe<F>*)b, (Fe<F>*)c, log_m, (hipStream_t)stream));
     return ZK_ERR_INVALID_ARG;
 }
 
+API int zk_field_modulus(zk_field_t f, void* out) {
+    if (!out) return ZK_ERR_INVALID_ARG;
+    FIELD_SWITCH(f, memcpy(out, F::P, sizeof(uint32_t) * F::N));
+    return ZK_OK;
+}
 API int zk_field_root_of_unity(zk_field_t f, uint32_t log_n, void* out) {
     if (!out) return ZK_ERR_INVALID_ARG;
     FIELD_SWITCH(f, {
@@ -355,18 +891,7 @@ API int zk_field_inverse(zk_field_t f, const void* a, void* out) {
 }
 API int zk_point_add(zk_curve_t c, const void* ja, const void* jb, void* jout) {
     if (!ja || !jb || !jout) return ZK_ERR_INVALID_ARG;
-    CURVE_SWITCH(c, {
-        Jacobian<C> a, b, r;
-        memcpy(&a, ja, 3 * 4 * coord_words<C>());
-        memcpy(&b, jb, 3 * 4 * coord_words<C>());
-        XYZZ<C> xa, xb;
-        jac_to_xyzz(xa, a);
-        jac_to_xyzz(xb, b);
-        xyzz_add(xa, xb);
-        xyzz_to_jacobian(r, xa);
-        memcpy(jout, &r, 3 * 4 * coord_words<C>());
-    });
-    return ZK_OK;
+    return point_add_host(c, ja, jb, jout);
 }
 API int zk_point_to_affine(zk_curve_t c, const void* jac, void* aff) {
     if (!jac || !aff) return ZK_ERR_INVALID_ARG;
@@ -383,27 +908,25 @@ API int zk_point_to_affine(zk_curve_t c, const void* jac, void* aff) {
 }
 
 API int zk_fixed_base_mul_device(zk_curve_t c, const void* d_scalars, uint64_t n, void* d_out, void* stream) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
     if (n == 0) return ZK_OK;
     if (!d_scalars || !d_out || !aligned16(d_scalars) || !aligned16(d_out) || n >= (1ull << 31)) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(d_out);
     CURVE_SWITCH(c, return fixed_base_run<C>((const Fe<typename C::Fr>*)d_scalars, n, (Affine<C>*)d_out, (hipStream_t)stream));
     return ZK_OK;
 }
 
 API int zk_fixed_base_msm_device(zk_curve_t c, const void* base_affine_mont, const void* d_scalars, uint64_t n, int scalars_are_montgomery,
                                  void* d_out, void* stream) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    ZK_TRY(require_init());
     if (n == 0) return ZK_OK;
     if (!d_scalars || !d_out || !aligned16(d_scalars) || !aligned16(d_out) || n >= (1ull << 31)) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(d_out);
     CURVE_SWITCH(c, {
         Affine<C> base;
         if (base_affine_mont)
             memcpy(&base, base_affine_mont, 2 * 4 * coord_words<C>());
         else
             curve_generator(base);
-        return fixed_base_msm_run<C>(base, (const Fe<typename C::Fr>*)d_scalars, n, scalars_are_montgomery ? 1 : 0, (Affine<C>*)d_out,
+        return fixed_base_msm_run<C>(dc, base, (const Fe<typename C::Fr>*)d_scalars, n, scalars_are_montgomery ? 1 : 0, (Affine<C>*)d_out,
                                      (hipStream_t)stream);
     });
     return ZK_OK;

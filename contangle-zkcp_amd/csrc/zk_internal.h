@@ -1,7 +1,7 @@
-// Internals shared by the translation units of libzkcp_amd.so: the process context (one GPU per
-// process), grow-only device workspaces, and the per-curve / per-field launch sequences that are
-// explicitly instantiated in zk_msm_inst.cc / zk_ntt_inst.cc (one TU per curve / field so the
-// gfx950 code objects build in parallel).
+// Internals shared by the translation units of libzkcp_amd.so: the process context (one DeviceCtx per GPU the
+// process drives), per-stream scratch, the pool of MSM jobs (deferred results: enqueue -> event -> collect), and the
+// per-curve / per-field launch sequences that are explicitly instantiated in zk_msm_inst.cc / zk_ntt_inst.cc (one TU
+// per curve / field so the gfx950 code objects build in parallel).
 #pragma once
 #include "zkcp_amd.h"
 
@@ -11,6 +11,7 @@
 
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -19,6 +20,7 @@
 
 namespace zk {
 
+struct DeviceCtx;
 
 #define HIP_TRY(expr)                                       \
     do {                                                    \
@@ -38,12 +40,15 @@ struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
 };
+struct BasesCopy {
+    void* dev = nullptr;     // affine points as uploaded (8 / 12 x u32 Montgomery words per coordinate)
+    void* dev29 = nullptr;   // the same points in the lazy-limb view (zk_curve29.h), built once at upload
+    bool owned = false;
+};
 struct BasesEntry {
     int curve;
-    void* dev;     // affine points as uploaded (8 / 12 x u32 Montgomery words per coordinate)
     uint64_t n;
-    bool owned;
-    void* dev29;   // the same points in the F29 view (zk_curve29.h), built once at upload for the 8-word G1 curves
+    std::vector<BasesCopy> per_dev;   // one resident copy per device of the process (the SRS is fixed: uploaded once)
 };
 struct TwKey {
     int field;
@@ -61,23 +66,87 @@ struct TwEntry {
     uint64_t stamp;
 };
 
-struct Ctx {
-    std::mutex mu;
-    bool inited = false;
+// resolved MSM plan knobs (zk_msm_opts; 0 / negative = choose automatically)
+struct MsmTuning {
+    int window_bits = 0, w0 = 0, w1 = 0;
+    int split_log = -1;
+    uint32_t slice_len = 0;
+    uint32_t big_thresh = 0;
+    int limb_bits = 0;        // 32 forces the saturated path
+    int waves = 0;
+    bool no_hot_help = false;
+};
+
+// One MSM in flight: its own device workspaces (so two jobs on two streams never share a buffer), a pinned host buffer
+// the per-window partial sums are copied to, the events of its phases and the per-curve routine that finishes it on the
+// host (Horner over the windows).  A job is reused only after it has been collected.
+struct MsmJob {
+    DeviceCtx* dc = nullptr;
+    bool busy = false;
+    uint64_t ticket = 0;
+    hipStream_t stream = nullptr;
+    DevBuf scalars_in;                // staging for scalars that arrive from the host or from a peer device
+    DevBuf hot, counts, digits, blockcnt, stage_idx, stage_low, queue, seg_out, subacc, sorted, buckets, part_a, part_b;
+    void* host_partials = nullptr;    // pinned
+    size_t host_cap = 0;
+    hipEvent_t ev[8];                 // [0] begin .. [5] reduced, [6] partials on the host, [7] accumulate kernel done
+    bool have_events = false;
+    // what collect needs
+    int (*finish)(MsmJob&, void* out_jac) = nullptr;
+    int curve = 0, c = 0, w0 = 0, nw = 0;
+    uint32_t per = 0;                 // partial sums per window
+    bool empty = true;                // nothing was launched (n == 0 or no windows): the result is the identity
+    zk_msm_profile prof;
+    double alg_bytes = 0;             // n x (scalar + affine point bytes) x share of the windows
+};
+
+// scratch that belongs to one caller stream (multi-pass NTT ping-pong buffer, fixed-base table / temporaries): two
+// NTTs on two streams run over different buffers
+struct StreamScratch {
+    hipStream_t stream = nullptr;
+    uint64_t stamp = 0;
+    DevBuf ntt_tmp, fb_table, fb_tmp;
+};
+
+constexpr int ZK_MAX_JOBS = 4;
+constexpr int ZK_MAX_STREAM_SCRATCH = 6;
+
+struct DeviceCtx {
     int device = -1;
-    int last_hip = 0;
+    int index = 0;            // position in Ctx::devs
     int num_cus = 0;
-    char info[256] = {0};
-    std::map<uint64_t, BasesEntry> bases;
-    uint64_t next_handle = 1;
+    std::mutex mu;            // serialises host-side enqueue on this device
     std::map<TwKey, TwEntry> tw;
     uint64_t tw_stamp = 0;
     size_t tw_bytes = 0;
-    // workspaces (grow-only, reused across calls)
-    DevBuf ntt_tmp, pow_tbl, fb_table, fb_tmp, msm_hot, msm_counts, msm_digits, msm_blockcnt, msm_stage_idx, msm_stage_low, msm_queue, msm_seg_out, msm_subacc, msm_sorted, msm_buckets, msm_part_a, msm_part_b, scratch_in, scratch_out;
-    hipEvent_t ev[6];   // MSM phase events
-    bool have_events = false;
-    zk_msm_profile prof;
+    DevBuf pow_tbl, scratch_in;
+    std::vector<std::unique_ptr<StreamScratch>> scratch;
+    uint64_t scratch_stamp = 0;
+    MsmJob jobs[ZK_MAX_JOBS];
+    hipStream_t side[2] = {nullptr, nullptr};   // library-owned streams: batched MSMs alternate between them
+    hipStream_t own = nullptr;                  // library-owned stream of a device that is not the caller's (multi-device fan-out)
+    hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
+    // NTT pass timing (zk_ntt_profile_enable): event pairs of the launches since the last read
+    std::vector<hipEvent_t> ntt_ev_pool;
+    size_t ntt_ev_used = 0;
+    uint64_t ntt_transforms = 0;
+    double ntt_alg_bytes = 0;
+};
+
+struct Ctx {
+    std::mutex mu;            // lifecycle, handles
+    bool inited = false;
+    int last_hip = 0;
+    char info[256] = {0};
+    std::vector<std::unique_ptr<DeviceCtx>> devs;
+    std::map<uint64_t, BasesEntry> bases;
+    uint64_t next_handle = 1;
+    uint64_t next_ticket = 1;
+    std::map<uint64_t, MsmJob*> tickets;
+    zk_msm_profile prof;      // of the last collected job
+    zk_ntt_opts ntt_opts;     // process-wide NTT plan knobs (zk_ntt_configure)
+    zk_msm_totals totals;     // sums over the collected jobs (zk_msm_profile_totals)
+    bool ntt_profile = false;
 };
 extern Ctx g;
 
@@ -128,25 +197,14 @@ void host_store(void* p, const Fe<F>& r) {
 inline int require_init() { return g.inited ? ZK_OK : ZK_ERR_NOT_INITIALIZED; }
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// HIP's current device is per host thread: every entry point binds the calling thread to the device it is about to use
+// (upstream callers arrive on rayon worker threads that have never seen hipSetDevice)
+inline int bind_device(DeviceCtx& dc) {
+    HIP_TRY(hipSetDevice(dc.device));
+    return ZK_OK;
+}
+int stream_scratch(DeviceCtx& dc, hipStream_t st, StreamScratch** out);   // zk_api.cc
 
-template <class F>
-int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st, const Fe<F>* g_pre = nullptr,
-            const Fe<F>* g_post = nullptr, uint32_t in_log = 0);
-template <class F>
-int coset_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st);
-template <class F>
-int vec_op_run(Fe<F>* a, const Fe<F>* b, const Fe<F>* c, uint64_t n, int op, const Fe<F>& s, hipStream_t st);
-template <class F>
-int witness_map_run(int field, Fe<F>* a, Fe<F>* b, Fe<F>* c, uint32_t logm, hipStream_t st);
-template <class C>
-int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
-            void* out_jac, hipStream_t st);
-template <class C>
-int bases_prepare_run(BasesEntry& be);   // build the resident F29 copy where the curve has one
-template <class C>
-int fixed_base_run(const Fe<typename C::Fr>* d_scalars, uint64_t n, Affine<C>* d_out, hipStream_t st);
-template <class C>
-int fixed_base_msm_run(const Affine<C>& base, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, Affine<C>* d_out, hipStream_t st);
 int msm_pick_c(uint64_t n, int requested);
 template <class C>
 inline int msm_windows(int c) {

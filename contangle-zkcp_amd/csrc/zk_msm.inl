@@ -1,6 +1,7 @@
 // MSM launch sequence and host tail.  Included by zk_msm_inst.cc, once per curve.
 #pragma once
 #include "zk_internal.h"
+#include "zk_msm_decl.h"
 #include "zk_host64.h"
 #include "zk_msm_kernels.h"
 namespace zk {
@@ -24,28 +25,74 @@ inline void partial_to_std(XYZZ<C>& r, const XYZZ<C29x2<C>>& p) {
     xyzz29_to_std<C>(r, p);
 }
 
-// C: the curve of the ABI call.  CK: the view the kernels compute in.  bases: device array of Affine<CK>.
+// Host tail of one MSM (per curve): Horner over the job's windows, high to low, then the shift by 2^(c*w0) -- on 64-bit
+// host limbs, from the per-window partial sums the job copied to pinned memory.  Runs in zk_msm_collect, i.e. after the
+// caller has had the chance to enqueue the next MSM: the GPU never waits for it.
 template <class C, class CK>
-int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
-                 void* out_jac, hipStream_t st) {
+int msm_finish_impl(MsmJob& job, void* out_jac) {
     Jacobian<C> result;
-    memset(&g.prof, 0, sizeof g.prof);
     XYZZ<C> total;
     xyzz_set_inf(total);
-    const int c = msm_pick_c(n, opts ? opts->window_bits : 0);
+    if (!job.empty) {
+        HIP_TRY(hipEventSynchronize(job.ev[6]));
+        const double t0 = now_ms();
+        const XYZZ<CK>* host = (const XYZZ<CK>*)job.host_partials;
+        HostXYZZ<C> htotal, hp;
+        to_host<C>(htotal, total);
+        for (int w = job.nw - 1; w >= 0; w--) {
+            for (int k = 0; k < job.c; k++) xyzz_dbl(htotal);
+            for (uint32_t i = 0; i < job.per; i++) {
+                XYZZ<C> ps;
+                partial_to_std<C>(ps, host[(size_t)w * job.per + i]);
+                to_host<C>(hp, ps);
+                xyzz_add(htotal, hp);
+            }
+        }
+        for (int k = 0; k < job.c * job.w0; k++) xyzz_dbl(htotal);
+        from_host<C>(total, htotal);
+        job.prof.host_tail_ms = (float)(now_ms() - t0);
+        hipEventElapsedTime(&job.prof.digits_ms, job.ev[0], job.ev[1]);
+        hipEventElapsedTime(&job.prof.hist_ms, job.ev[1], job.ev[2]);
+        hipEventElapsedTime(&job.prof.scatter_ms, job.ev[2], job.ev[3]);
+        hipEventElapsedTime(&job.prof.accumulate_ms, job.ev[3], job.ev[4]);
+        hipEventElapsedTime(&job.prof.accumulate_kernel_ms, job.ev[3], job.ev[7]);
+        hipEventElapsedTime(&job.prof.reduce_ms, job.ev[4], job.ev[5]);
+        hipEventElapsedTime(&job.prof.total_ms, job.ev[0], job.ev[5]);
+        job.prof.total_ms += job.prof.host_tail_ms;
+        job.prof.groups = 1;
+    }
+    xyzz_to_jacobian(result, total);
+    memcpy(out_jac, &result, 3 * sizeof(uint32_t) * coord_words<C>());
+    return ZK_OK;
+}
+
+// C: the curve of the ABI call.  CK: the view the kernels compute in.  bases: device array of Affine<CK>.
+// Enqueues every kernel of the MSM and the copy of the per-window partial sums on job.stream and returns; no host
+// synchronisation (workspace growth aside).
+template <class C, class CK>
+int msm_enqueue_impl(MsmJob& job, const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
+    hipStream_t st = job.stream;
+    memset(&job.prof, 0, sizeof job.prof);
+    job.finish = &msm_finish_impl<C, CK>;
+    job.empty = true;
+    const int c = msm_pick_c(n, tu.window_bits);
     const int nwin = msm_windows<C>(c);
     int w0 = 0, w1 = nwin;
-    if (opts && !(opts->window_begin == 0 && opts->window_end == 0)) {
-        w0 = opts->window_begin;
-        w1 = opts->window_end;
+    if (!(tu.w0 == 0 && tu.w1 == 0)) {
+        w0 = tu.w0;
+        w1 = tu.w1;
         if (w0 < 0 || w1 > nwin || w0 > w1) return ZK_ERR_INVALID_ARG;
     }
-    g.prof.window_bits = c;
-    g.prof.windows_total = nwin;
-    g.prof.windows_done = w1 - w0;
-    g.prof.limb_bits = CK::EXT >= 29 ? 29 : 32;
+    job.c = c;
+    job.w0 = w0;
+    job.nw = w1 - w0;
+    job.prof.window_bits = c;
+    job.prof.windows_total = nwin;
+    job.prof.windows_done = w1 - w0;
+    job.prof.limb_bits = CK::EXT >= 29 ? 29 : 32;
     if (n > 0 && w1 > w0) {
         if (n >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
+        const int num_cus = job.dc->num_cus > 0 ? job.dc->num_cus : 256;
         MsmShape sh;
         sh.n = (uint32_t)n;
         sh.c = c;
@@ -57,11 +104,7 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         sh.mont = mont;
         {   // oversize threshold: 2x the mean bucket length + 64 (uniform 2^20 / c=16: mean 32, max ~70 -> none)
             const uint64_t mean = n / sh.nbk;
-            sh.big_thresh = (uint32_t)(2 * mean + 64);
-            if (const char* e = getenv("ZK_MSM_BIG")) {
-                int v = atoi(e);
-                if (v >= 1) sh.big_thresh = (uint32_t)v;
-            }
+            sh.big_thresh = tu.big_thresh ? tu.big_thresh : (uint32_t)(2 * mean + 64);
         }
         const int nw_all = sh.nw;
         // Bucket splitting: with fewer than ~4 work items per resident lane the accumulate kernel ends in a long drain (every
@@ -72,15 +115,12 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         // i.e. halves while there are fewer than 8 buckets per lane, quarters below one bucket per lane, pieces never
         // shorter than 8 entries on average.
         {
-            const uint64_t lanes = (uint64_t)(g.num_cus > 0 ? g.num_cus : 256) * 4 * 3 * 64;
+            const uint64_t lanes = (uint64_t)num_cus * 4 * 3 * 64;
             const uint64_t items = (uint64_t)nw_all * sh.nbk;
             int sl = 0;
             if (items < 8 * lanes && (n >> 1) / sh.nbk >= 8) sl = 1;
             if (items < lanes && (n >> 2) / sh.nbk >= 8) sl = 2;
-            if (const char* e = getenv("ZK_MSM_SPLIT")) {
-                int v = atoi(e);
-                if (v >= 0 && v <= 4) sl = v;
-            }
+            if (tu.split_log >= 0) sl = tu.split_log > 4 ? 4 : tu.split_log;
             sh.split_log = sl;
         }
         const uint32_t nbuckets = (uint32_t)nw_all * sh.nbk;
@@ -89,28 +129,28 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         if (nreg > 4096 || sh.nranges > 64) return ZK_ERR_UNSUPPORTED;         // LDS tables of those kernels (c <= 16: <= 1024, 64)
         if ((uint64_t)n * (uint64_t)nw_all >= (1ull << 32)) return ZK_ERR_UNSUPPORTED;   // entry positions are u32 (2^27 points x 16 windows fit)
         // counts | offs | order | wg_total | region_base
-        ZK_TRY(ws_get(g.msm_counts, ((size_t)nbuckets * 3 + 2 * (size_t)nreg) * 4));
-        uint32_t* counts = (uint32_t*)g.msm_counts.p;
+        ZK_TRY(ws_get(job.counts, ((size_t)nbuckets * 3 + 2 * (size_t)nreg) * 4));
+        uint32_t* counts = (uint32_t*)job.counts.p;
         uint32_t* offs = counts + nbuckets;
         uint32_t* order = offs + nbuckets;
         uint32_t* wg_total = order + nbuckets;
         uint32_t* region_base = wg_total + nreg;
-        ZK_TRY(ws_get(g.msm_blockcnt, (size_t)nreg * nblocks * 4));
-        uint32_t* blockcnt = (uint32_t*)g.msm_blockcnt.p;
-        ZK_TRY(ws_get(g.msm_stage_idx, (size_t)n * nw_all * 4));
-        ZK_TRY(ws_get(g.msm_stage_low, (size_t)n * nw_all * 2));
-        ZK_TRY(ws_get(g.msm_digits, (size_t)n * nw_all * 2));
-        uint16_t* digits = (uint16_t*)g.msm_digits.p;
-        uint32_t* stage_idx = (uint32_t*)g.msm_stage_idx.p;
-        uint16_t* stage_low = (uint16_t*)g.msm_stage_low.p;
-        ZK_TRY(ws_get(g.msm_sorted, (size_t)n * nw_all * 4));
-        uint32_t* sorted = (uint32_t*)g.msm_sorted.p;
-        ZK_TRY(ws_get(g.msm_buckets, (size_t)nbuckets * sizeof(XYZZ<CK>)));
-        XYZZ<CK>* buckets = (XYZZ<CK>*)g.msm_buckets.p;
+        ZK_TRY(ws_get(job.blockcnt, (size_t)nreg * nblocks * 4));
+        uint32_t* blockcnt = (uint32_t*)job.blockcnt.p;
+        ZK_TRY(ws_get(job.stage_idx, (size_t)n * nw_all * 4));
+        ZK_TRY(ws_get(job.stage_low, (size_t)n * nw_all * 2));
+        ZK_TRY(ws_get(job.digits, (size_t)n * nw_all * 2));
+        uint16_t* digits = (uint16_t*)job.digits.p;
+        uint32_t* stage_idx = (uint32_t*)job.stage_idx.p;
+        uint16_t* stage_low = (uint16_t*)job.stage_low.p;
+        ZK_TRY(ws_get(job.sorted, (size_t)n * nw_all * 4));
+        uint32_t* sorted = (uint32_t*)job.sorted.p;
+        ZK_TRY(ws_get(job.buckets, (size_t)nbuckets * sizeof(XYZZ<CK>)));
+        XYZZ<CK>* buckets = (XYZZ<CK>*)job.buckets.p;
         XYZZ<CK>* acc_out = buckets;
         if (sh.split_log > 0) {
-            ZK_TRY(ws_get(g.msm_subacc, ((size_t)nbuckets << sh.split_log) * sizeof(XYZZ<CK>)));
-            acc_out = (XYZZ<CK>*)g.msm_subacc.p;
+            ZK_TRY(ws_get(job.subacc, ((size_t)nbuckets << sh.split_log) * sizeof(XYZZ<CK>)));
+            acc_out = (XYZZ<CK>*)job.subacc.p;
         }
         // slice length of the bucket reduction: 64K lanes = one wave on every SIMD, which is what saturates the VALUs
         // (the kernel is instruction-throughput-bound, not latency-bound); a rank of a window-sharded MSM owns few
@@ -118,36 +158,30 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         uint32_t L = (uint32_t)(((uint64_t)nw_all * sh.nbk) >> 16);
         if (L < 1) L = 1;
         if (L > 8) L = 8;
-        if (const char* e = getenv("ZK_MSM_SLICE")) {
-            int v = atoi(e);
-            if (v >= 1 && v <= 1024) L = (uint32_t)v;
-        }
+        if (tu.slice_len >= 1 && tu.slice_len <= 1024) L = tu.slice_len;
         if (L > sh.nbk) L = sh.nbk;
         const uint32_t spw = (sh.nbk + L - 1) / L;                  // slices per window
         const uint32_t pbw = spw / 128 + 2;                          // second ping-pong buffer, points per window
-        ZK_TRY(ws_get(g.msm_part_a, (size_t)spw * nw_all * sizeof(XYZZ<CK>)));
-        ZK_TRY(ws_get(g.msm_part_b, (size_t)pbw * nw_all * sizeof(XYZZ<CK>)));
+        ZK_TRY(ws_get(job.part_a, (size_t)spw * nw_all * sizeof(XYZZ<CK>)));
+        ZK_TRY(ws_get(job.part_b, (size_t)pbw * nw_all * sizeof(XYZZ<CK>)));
         // oversized-bucket lists: a bucket above big_thresh yields ceil(cnt / MSM_SEG) segments
         const size_t max_seg = ((size_t)n / MSM_SEG + (size_t)n / sh.big_thresh + 2) * nw_all;
-        ZK_TRY(ws_get(g.msm_queue, sizeof(MsmQueue) + max_seg * (sizeof(MsmSeg) + 8) + 64));
-        ZK_TRY(ws_get(g.msm_seg_out, max_seg * sizeof(XYZZ<CK>)));
-        MsmQueue* q = (MsmQueue*)g.msm_queue.p;
+        ZK_TRY(ws_get(job.queue, sizeof(MsmQueue) + max_seg * (sizeof(MsmSeg) + 8) + 64));
+        ZK_TRY(ws_get(job.seg_out, max_seg * sizeof(XYZZ<CK>)));
+        MsmQueue* q = (MsmQueue*)job.queue.p;
         MsmSeg* seg_list = (MsmSeg*)(q + 1);
         uint32_t* big_list = (uint32_t*)(seg_list + max_seg);
-        XYZZ<CK>* seg_out = (XYZZ<CK>*)g.msm_seg_out.p;
-        XYZZ<CK>* cur = (XYZZ<CK>*)g.msm_part_a.p;
-        XYZZ<CK>* nxt = (XYZZ<CK>*)g.msm_part_b.p;
-        if (!g.have_events) {
-            for (auto& e : g.ev) HIP_TRY(hipEventCreate(&e));
-            g.have_events = true;
+        XYZZ<CK>* seg_out = (XYZZ<CK>*)job.seg_out.p;
+        XYZZ<CK>* cur = (XYZZ<CK>*)job.part_a.p;
+        XYZZ<CK>* nxt = (XYZZ<CK>*)job.part_b.p;
+        if (!job.have_events) {
+            for (auto& e : job.ev) HIP_TRY(hipEventCreate(&e));
+            job.have_events = true;
         }
-        // resident waves per SIMD = what the kernel was compiled for (msm_acc_waves); ZK_MSM_WAVES launches fewer
+        // resident waves per SIMD = what the kernel was compiled for (msm_acc_waves); opts.waves_per_simd launches fewer
         unsigned waves_per_simd = (unsigned)msm_acc_waves<CK>();
-        if (const char* e = getenv("ZK_MSM_WAVES")) {
-            int v = atoi(e);
-            if (v >= 1 && v <= 8) waves_per_simd = (unsigned)v;
-        }
-        hipEvent_t* ev = g.ev;   // [0] begin, [1] counted, [2] staged, [3] sorted, [4] accumulated, [5] reduced
+        if (tu.waves >= 1 && tu.waves <= 8) waves_per_simd = (unsigned)tu.waves;
+        hipEvent_t* ev = job.ev;   // [0] begin, [1] counted, [2] staged, [3] sorted, [4] accumulated, [5] reduced, [6] partials on the host
         HIP_TRY(hipEventRecord(ev[0], st));
         // ---- sort: partition the digits by (window, bucket range), then counting-sort every region in LDS
         const unsigned dblk = n >= 8192 ? 1024u : 256u;   // small problems: fewer lanes, cheaper barriers
@@ -173,7 +207,7 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         const uint64_t cl64 = 4 * (n / sh.nranges) + 4 * (uint64_t)cap;
         const uint32_t chunk_limit = cl64 < 0xffffffffull ? (uint32_t)cl64 : 0xffffffffu;
         // hot regions (skewed witnesses) are histogrammed and scattered by MSM_HOT_SLICES workgroups each, around the sort kernel
-        const bool hot_help = nreg <= 1024 && !getenv("ZK_MSM_NO_HOT_HELP");
+        const bool hot_help = nreg <= 1024 && !tu.no_hot_help;
         uint32_t* hot_flag = nullptr;
         uint32_t* hot_list = nullptr;
         uint32_t* gcur = nullptr;
@@ -181,8 +215,8 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         if (hot_slices < 1) hot_slices = 1;
         if (hot_slices > MSM_HOT_SLICES) hot_slices = MSM_HOT_SLICES;
         if (hot_help) {
-            ZK_TRY(ws_get(g.msm_hot, ((size_t)nreg + 1 + MSM_HOT_MAX + nbuckets) * 4));
-            hot_flag = (uint32_t*)g.msm_hot.p;
+            ZK_TRY(ws_get(job.hot, ((size_t)nreg + 1 + MSM_HOT_MAX + nbuckets) * 4));
+            hot_flag = (uint32_t*)job.hot.p;
             hot_list = hot_flag + nreg;
             gcur = hot_list + 1 + MSM_HOT_MAX;
             HIP_TRY(hipMemsetAsync(counts, 0, (size_t)nbuckets * 4, st));
@@ -198,15 +232,16 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
             ZK_LAUNCH((msm_hot_kernel<void>), MSM_HOT_MAX * hot_slices, 1024, (size_t)2 * sh.rb * 4, st, (const uint32_t*)stage_idx,
                       (const uint16_t*)stage_low, sh, (const uint32_t*)region_base, (const uint32_t*)wg_total, (const uint32_t*)hot_list, counts,
                       gcur, sorted, 1, hot_slices);
-        HIP_TRY(hipEventRecord(ev[3], st));
+        HIP_TRY(hipMemsetAsync(q, 0, sizeof(MsmQueue), st));
+        HIP_TRY(hipEventRecord(ev[3], st));   // [3] -> [7] brackets the accumulate kernel alone
         // ---- persistent accumulate: lanes stream buckets, largest first; oversized buckets go to the cooperative segment
         // kernels (fixed grids over device-side lists, no host round trip)
-        HIP_TRY(hipMemsetAsync(q, 0, sizeof(MsmQueue), st));
         const uint32_t ntasks = (((nreg * ((sh.rb + MSM_RANKW - 1) / MSM_RANKW) * MSM_RANKW) << sh.split_log) + MSM_BATCH - 1) / MSM_BATCH;  // batches in the queue
-        unsigned acc_grid = (g.num_cus > 0 ? (unsigned)g.num_cus : 256u) * 4u * waves_per_simd;
+        unsigned acc_grid = (unsigned)num_cus * 4u * waves_per_simd;
         if (acc_grid > ntasks) acc_grid = ntasks;
         ZK_LAUNCH((msm_accumulate_kernel<CK>), acc_grid, 64, 0, st, bases, (const uint32_t*)sorted, (const uint32_t*)offs,
                   (const uint32_t*)counts, (const uint32_t*)order, acc_out, sh, q, seg_list, big_list);
+        HIP_TRY(hipEventRecord(ev[7], st));
         if (sh.split_log > 0)
             ZK_LAUNCH((msm_combine_sub_kernel<CK>), (nbuckets + 63) / 64, 64, 0, st, (const XYZZ<CK>*)acc_out, buckets, nbuckets, sh.split_log);
         const unsigned big_grid = max_seg < 4096 ? (unsigned)max_seg : 4096u;
@@ -231,77 +266,56 @@ int msm_run_impl(const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, u
         }
         HIP_TRY(hipEventRecord(ev[5], st));
         HIP_TRY(hipGetLastError());
-        std::vector<XYZZ<CK>> host((size_t)nw_all * per);
-        HIP_TRY(hipMemcpyAsync(host.data(), cur, host.size() * sizeof(XYZZ<CK>), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        const double t0 = now_ms();
-        // Horner over this call's windows, high to low, then the shift by 2^(c*w0) -- on 64-bit host limbs
-        HostXYZZ<C> htotal, hp;
-        to_host<C>(htotal, total);
-        for (int w = nw_all - 1; w >= 0; w--) {
-            for (int k = 0; k < c; k++) xyzz_dbl(htotal);
-            for (uint32_t i = 0; i < per; i++) {
-                XYZZ<C> ps;
-                partial_to_std<C>(ps, host[(size_t)w * per + i]);
-                to_host<C>(hp, ps);
-                xyzz_add(htotal, hp);
-            }
+        const size_t hbytes = (size_t)nw_all * per * sizeof(XYZZ<CK>);
+        if (job.host_cap < hbytes) {
+            if (job.host_partials) hipHostFree(job.host_partials);
+            job.host_partials = nullptr;
+            job.host_cap = 0;
+            HIP_TRY(hipHostMalloc(&job.host_partials, hbytes + 4096, 0));
+            job.host_cap = hbytes + 4096;
         }
-        for (int k = 0; k < c * w0; k++) xyzz_dbl(htotal);
-        from_host<C>(total, htotal);
-        g.prof.host_tail_ms = (float)(now_ms() - t0);
-        hipEventElapsedTime(&g.prof.digits_ms, ev[0], ev[1]);
-        hipEventElapsedTime(&g.prof.hist_ms, ev[1], ev[2]);
-        hipEventElapsedTime(&g.prof.scatter_ms, ev[2], ev[3]);
-        hipEventElapsedTime(&g.prof.accumulate_ms, ev[3], ev[4]);
-        hipEventElapsedTime(&g.prof.reduce_ms, ev[4], ev[5]);
-        hipEventElapsedTime(&g.prof.total_ms, ev[0], ev[5]);
-        g.prof.total_ms += g.prof.host_tail_ms;
-        g.prof.groups = 1;
+        HIP_TRY(hipMemcpyAsync(job.host_partials, cur, hbytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(ev[6], st));
+        job.per = per;
+        job.empty = false;
+        job.alg_bytes = (double)n * (sizeof(Fe<typename C::Fr>) + sizeof(Affine<C>)) * (double)(w1 - w0) / (double)nwin;
     }
-    xyzz_to_jacobian(result, total);
-    memcpy(out_jac, &result, 3 * sizeof(uint32_t) * coord_words<C>());
     return ZK_OK;
 }
 
 
 // every curve runs its bucket arithmetic in the lazy-limb view (Pallas, Vesta, BN254: 9 x 29-bit limbs; BLS12-381: 14 x 28;
-// G2 as pairs of those); ZK_MSM_F29=0 forces the saturated 32-bit path
+// G2 as pairs of those); zk_msm_opts.limb_bits = 32 forces the saturated 32-bit path
 template <class C>
 constexpr bool has_f29() {
     return C::EXT == 1 || C::EXT == 2;
 }
-inline bool f29_enabled() {
-    const char* e = getenv("ZK_MSM_F29");   // "0" forces the saturated 32-bit path (A/B measurements, tests)
-    return !(e && e[0] == '0');
-}
-
 template <class C>
-int bases_prepare_run(BasesEntry& be) {
-    be.dev29 = nullptr;
+int bases_prepare_run(BasesCopy& bc, uint64_t n) {
+    bc.dev29 = nullptr;
     if constexpr (has_f29<C>()) {
-        if (be.n == 0) return ZK_OK;
+        if (n == 0) return ZK_OK;
         void* d = nullptr;
-        HIP_TRY(hipMalloc(&d, sizeof(Affine<F29View<C>>) * be.n));
-        ZK_LAUNCH((bases_to29_kernel<C>), (unsigned)((be.n + 255) / 256), 256, 0, (hipStream_t)0, (const Affine<C>*)be.dev,
-                  (Affine<F29View<C>>*)d, be.n);
+        HIP_TRY(hipMalloc(&d, sizeof(Affine<F29View<C>>) * n));
+        ZK_LAUNCH((bases_to29_kernel<C>), (unsigned)((n + 255) / 256), 256, 0, (hipStream_t)0, (const Affine<C>*)bc.dev,
+                  (Affine<F29View<C>>*)d, n);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess) {
             hipFree(d);
             return ZK_ERR_HIP;
         }
-        be.dev29 = d;
+        bc.dev29 = d;
     }
     return ZK_OK;
 }
 
+// every curve runs its bucket arithmetic in the lazy-limb view unless opts.limb_bits = 32 asks for the saturated words
 template <class C>
-int msm_run(const BasesEntry& be, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
-            void* out_jac, hipStream_t st) {
+int msm_enqueue(MsmJob& job, const BasesCopy& bc, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
     if constexpr (has_f29<C>()) {
-        if (be.dev29 && f29_enabled())
-            return msm_run_impl<C, F29View<C>>((const Affine<F29View<C>>*)be.dev29, d_scalars, n, mont, opts, out_jac, st);
+        if (bc.dev29 && tu.limb_bits != 32)
+            return msm_enqueue_impl<C, F29View<C>>(job, (const Affine<F29View<C>>*)bc.dev29, d_scalars, n, mont, tu);
     }
-    return msm_run_impl<C, C>((const Affine<C>*)be.dev, d_scalars, n, mont, opts, out_jac, st);
+    return msm_enqueue_impl<C, C>(job, (const Affine<C>*)bc.dev, d_scalars, n, mont, tu);
 }
 
 template <class C>
@@ -312,12 +326,15 @@ int fixed_base_run(const Fe<typename C::Fr>* d_scalars, uint64_t n, Affine<C>* d
 }
 // ark-ec 0.3 FixedBaseMSM (window table + multi_scalar_mul) + batch_normalization_into_affine for one base
 template <class C>
-int fixed_base_msm_run(const Affine<C>& base, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, Affine<C>* d_out, hipStream_t st) {
+int fixed_base_msm_run(DeviceCtx& dc, const Affine<C>& base, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, Affine<C>* d_out,
+                       hipStream_t st) {
     const uint32_t entries = (uint32_t)fb_windows<C>() * FB_ROW;
-    ZK_TRY(ws_get(g.fb_table, (size_t)entries * sizeof(Affine<C>)));
-    ZK_TRY(ws_get(g.fb_tmp, (size_t)n * sizeof(XYZZ<C>)));
-    Affine<C>* table = (Affine<C>*)g.fb_table.p;
-    XYZZ<C>* tmp = (XYZZ<C>*)g.fb_tmp.p;
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));   // table and temporaries belong to the caller's stream
+    ZK_TRY(ws_get(ss->fb_table, (size_t)entries * sizeof(Affine<C>)));
+    ZK_TRY(ws_get(ss->fb_tmp, (size_t)n * sizeof(XYZZ<C>)));
+    Affine<C>* table = (Affine<C>*)ss->fb_table.p;
+    XYZZ<C>* tmp = (XYZZ<C>*)ss->fb_tmp.p;
     ZK_LAUNCH((fixed_base_table_kernel<C>), (entries + 63) / 64, 64, 0, st, base, table, entries);
     ZK_LAUNCH((fixed_base_msm_kernel<C>), (unsigned)((n + 63) / 64), 64, 0, st, (const Affine<C>*)table, d_scalars, tmp, (uint32_t)n, mont);
     const uint64_t lanes = (n + FB_K - 1) / FB_K;

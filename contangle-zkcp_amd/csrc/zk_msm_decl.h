@@ -1,0 +1,15 @@
+// Launch sequences of the curve side (MSM, fixed-base), instantiated per curve in zk_msm_inst.cc.
+#pragma once
+#include "zk_internal.h"
+namespace zk {
+// enqueue the device work of one MSM on job.stream; the result is produced by job.finish after the job's last event
+template <class C>
+int msm_enqueue(MsmJob& job, const BasesCopy& bc, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu);
+template <class C>
+int bases_prepare_run(BasesCopy& bc, uint64_t n);   // build the resident lazy-limb copy
+template <class C>
+int fixed_base_run(const Fe<typename C::Fr>* d_scalars, uint64_t n, Affine<C>* d_out, hipStream_t st);
+template <class C>
+int fixed_base_msm_run(DeviceCtx& dc, const Affine<C>& base, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, Affine<C>* d_out,
+                       hipStream_t st);
+}  // namespace zk

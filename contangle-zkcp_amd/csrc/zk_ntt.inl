@@ -1,6 +1,7 @@
 // NTT launch sequence (plan -> passes).  Included by zk_ntt_inst.cc, once per scalar field.
 #pragma once
 #include "zk_internal.h"
+#include "zk_ntt_decl.h"
 #include "zk_ntt_kernels.h"
 namespace zk {
 // ------------------------------------------------------------------ NTT
@@ -15,10 +16,7 @@ inline NttPlan ntt_plan(uint32_t logn) {
     NttPlan p;
     memset(&p, 0, sizeof p);
     int max_r = 10;
-    if (const char* e = getenv("ZK_NTT_MAX_LOGR")) {
-        int v = atoi(e);
-        if (v >= 1 && v <= 10) max_r = v;
-    }
+    if (g.ntt_opts.max_log_radix >= 1 && g.ntt_opts.max_log_radix <= 10) max_r = g.ntt_opts.max_log_radix;
     int nd = (int)((logn + max_r - 1) / max_r);
     if (nd < 1) nd = 1;
     p.nd = nd;
@@ -29,10 +27,7 @@ inline NttPlan ntt_plan(uint32_t logn) {
         rem -= r;
     }
     int want_t = 2;
-    if (const char* e = getenv("ZK_NTT_LOGT")) {
-        int v = atoi(e);
-        if (v >= 0 && v <= 4) want_t = v;
-    }
+    if (g.ntt_opts.log_tile_plus1 >= 1 && g.ntt_opts.log_tile_plus1 <= 5) want_t = g.ntt_opts.log_tile_plus1 - 1;
     int log_m = 0;
     for (int i = 0; i < nd; i++) {
         int lt = want_t;
@@ -52,27 +47,27 @@ inline NttPlan ntt_plan(uint32_t logn) {
 }
 
 template <class F>
-int tw_table(const Fe<F>& omega, uint32_t logn, int field, hipStream_t st, const Fe<F>** out) {
+int tw_table(DeviceCtx& dc, const Fe<F>& omega, uint32_t logn, int field, hipStream_t st, const Fe<F>** out) {
     TwKey key;
     memset(&key, 0, sizeof key);
     key.field = field;
     key.logn = logn;
     memcpy(key.omega, omega.v, sizeof(uint32_t) * F::N);
-    auto it = g.tw.find(key);
-    if (it != g.tw.end()) {
-        it->second.stamp = ++g.tw_stamp;
+    auto it = dc.tw.find(key);
+    if (it != dc.tw.end()) {
+        it->second.stamp = ++dc.tw_stamp;
         *out = (const Fe<F>*)it->second.dev;
         return ZK_OK;
     }
     // evict least-recently-used tables beyond 8 entries / 2 GiB
-    while (g.tw.size() >= 8 || g.tw_bytes > (2ull << 30)) {
-        auto victim = g.tw.begin();
-        for (auto i2 = g.tw.begin(); i2 != g.tw.end(); ++i2)
+    while (dc.tw.size() >= 8 || dc.tw_bytes > (2ull << 30)) {
+        auto victim = dc.tw.begin();
+        for (auto i2 = dc.tw.begin(); i2 != dc.tw.end(); ++i2)
             if (i2->second.stamp < victim->second.stamp) victim = i2;
         HIP_TRY(hipStreamSynchronize(st));
         hipFree(victim->second.dev);
-        g.tw_bytes -= victim->second.bytes;
-        g.tw.erase(victim);
+        dc.tw_bytes -= victim->second.bytes;
+        dc.tw.erase(victim);
     }
     const uint64_t count = logn > 0 ? (1ull << (logn - 1)) : 1;
     const int nbits = logn > 0 ? (int)logn - 1 : 0;
@@ -83,41 +78,41 @@ int tw_table(const Fe<F>& omega, uint32_t logn, int field, hipStream_t st, const
         tbl[k] = w;
         fe_sqr(w, w);
     }
-    ZK_TRY(ws_get(g.pow_tbl, sizeof(Fe<F>) * 64));
-    HIP_TRY(hipMemcpyAsync(g.pow_tbl.p, tbl.data(), sizeof(Fe<F>) * tbl.size(), hipMemcpyHostToDevice, st));
+    ZK_TRY(ws_get(dc.pow_tbl, sizeof(Fe<F>) * 64));
+    HIP_TRY(hipMemcpyAsync(dc.pow_tbl.p, tbl.data(), sizeof(Fe<F>) * tbl.size(), hipMemcpyHostToDevice, st));
     void* dev = nullptr;
     HIP_TRY(hipMalloc(&dev, sizeof(Fe<F>) * count));
     const unsigned blk = 256;
-    ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((count + blk - 1) / blk), blk, 0, st, (Fe<F>*)dev, (const Fe<F>*)g.pow_tbl.p,
+    ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((count + blk - 1) / blk), blk, 0, st, (Fe<F>*)dev, (const Fe<F>*)dc.pow_tbl.p,
               count, nbits);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // pow_tbl is reused by the next table build
-    TwEntry e{dev, sizeof(Fe<F>) * count, ++g.tw_stamp};
-    g.tw[key] = e;
-    g.tw_bytes += e.bytes;
+    TwEntry e{dev, sizeof(Fe<F>) * count, ++dc.tw_stamp};
+    dc.tw[key] = e;
+    dc.tw_bytes += e.bytes;
     *out = (const Fe<F>*)dev;
     return ZK_OK;
 }
 
 // device tables lo[j] = g^j (j < min(n,1024)), hi[j] = g^(1024 j) (j < max(1, n/1024)) for on-the-fly coset powers; cached
 template <class F>
-int pow_tables(const Fe<F>& gshift, uint32_t logn, int field, hipStream_t st, PowTables<F>* out) {
+int pow_tables(DeviceCtx& dc, const Fe<F>& gshift, uint32_t logn, int field, hipStream_t st, PowTables<F>* out) {
     TwKey key;
     memset(&key, 0, sizeof key);
     key.field = field | 0x100;   // separate key space from the twiddle tables
     key.logn = logn;
     memcpy(key.omega, gshift.v, sizeof(uint32_t) * F::N);
-    auto it = g.tw.find(key);
+    auto it = dc.tw.find(key);
     const uint64_t nlo = logn >= 10 ? 1024 : (1ull << logn), nhi = logn > 10 ? (1ull << (logn - 10)) : 1;
-    if (it == g.tw.end()) {
-        while (g.tw.size() >= 16 || g.tw_bytes > (2ull << 30)) {
-            auto victim = g.tw.begin();
-            for (auto i2 = g.tw.begin(); i2 != g.tw.end(); ++i2)
+    if (it == dc.tw.end()) {
+        while (dc.tw.size() >= 16 || dc.tw_bytes > (2ull << 30)) {
+            auto victim = dc.tw.begin();
+            for (auto i2 = dc.tw.begin(); i2 != dc.tw.end(); ++i2)
                 if (i2->second.stamp < victim->second.stamp) victim = i2;
             HIP_TRY(hipStreamSynchronize(st));
             hipFree(victim->second.dev);
-            g.tw_bytes -= victim->second.bytes;
-            g.tw.erase(victim);
+            dc.tw_bytes -= victim->second.bytes;
+            dc.tw.erase(victim);
         }
         // 2^k power ladders of g (10 entries) and of g^1024 (logn - 10 entries), then two table kernels
         std::vector<Fe<F>> lad(64);
@@ -139,12 +134,12 @@ int pow_tables(const Fe<F>& gshift, uint32_t logn, int field, hipStream_t st, Po
         ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nhi + 255) / 256), 256, 0, st, (Fe<F>*)dev + nlo, (const Fe<F>*)(d_lad + 32), nhi, 22);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));   // `lad` is a host temporary
-        TwEntry e{dev, bytes, ++g.tw_stamp};
-        g.tw[key] = e;
-        g.tw_bytes += bytes;
-        it = g.tw.find(key);
+        TwEntry e{dev, bytes, ++dc.tw_stamp};
+        dc.tw[key] = e;
+        dc.tw_bytes += bytes;
+        it = dc.tw.find(key);
     }
-    it->second.stamp = ++g.tw_stamp;
+    it->second.stamp = ++dc.tw_stamp;
     out->lo = (const Fe<F>*)it->second.dev;
     out->hi = (const Fe<F>*)it->second.dev + nlo;
     return ZK_OK;
@@ -152,15 +147,15 @@ int pow_tables(const Fe<F>& gshift, uint32_t logn, int field, hipStream_t st, Po
 
 // size-2^logn DFT of `a` with root omega; optionally fused with a[i] *= g_pre^i before and a[k] *= g_post^k after
 template <class F>
-int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st, const Fe<F>* g_pre,
+int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st, const Fe<F>* g_pre,
             const Fe<F>* g_post, uint32_t in_log) {
+    if (logn > (uint32_t)F::TWO_ADICITY || logn > 30) return ZK_ERR_INVALID_ARG;   // before anything is sized from logn
     if (logn == 0) return ZK_OK;  // size-1 transform is the identity, n^-1 = 1 and g^0 = 1
     PowTables<F> tpre{nullptr, nullptr}, tpost{nullptr, nullptr};
-    if (g_pre) ZK_TRY(pow_tables<F>(*g_pre, logn, field, st, &tpre));
-    if (g_post) ZK_TRY(pow_tables<F>(*g_post, logn, field, st, &tpost));
-    if (logn > (uint32_t)F::TWO_ADICITY || logn > 30) return ZK_ERR_INVALID_ARG;
+    if (g_pre) ZK_TRY(pow_tables<F>(dc, *g_pre, logn, field, st, &tpre));
+    if (g_post) ZK_TRY(pow_tables<F>(dc, *g_post, logn, field, st, &tpost));
     const Fe<F>* tw = nullptr;
-    ZK_TRY(tw_table<F>(omega, logn, field, st, &tw));
+    ZK_TRY(tw_table<F>(dc, omega, logn, field, st, &tw));
     Fe<F> scale;
     fe_one(scale);
     if (scale_flag) {
@@ -173,8 +168,10 @@ int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_fl
     NttPlan plan = ntt_plan(logn);
     Fe<F>* tmp = nullptr;
     if (plan.nd > 1) {
-        ZK_TRY(ws_get(g.ntt_tmp, sizeof(Fe<F>) << logn));
-        tmp = (Fe<F>*)g.ntt_tmp.p;
+        StreamScratch* ss = nullptr;
+        ZK_TRY(stream_scratch(dc, st, &ss));   // the ping-pong buffer belongs to the caller's stream
+        ZK_TRY(ws_get(ss->ntt_tmp, sizeof(Fe<F>) << logn));
+        tmp = (Fe<F>*)ss->ntt_tmp.p;
     }
     int log_m = 0;
     for (int p = 0; p < plan.nd; p++) {
@@ -209,8 +206,8 @@ int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_fl
         const uint64_t tiles = (1ull << logn) >> (A.log_r + A.log_t);
         const uint32_t rt = 1u << (A.log_r + A.log_t);
         unsigned max_blk = 512;  // 8 waves per tile: measured best (tools/tune_ntt.py)
-        if (const char* e = getenv("ZK_NTT_BLOCK")) {
-            int v = atoi(e);
+        {
+            const int v = g.ntt_opts.block;
             if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) max_blk = (unsigned)v;
         }
         unsigned blk = rt / 2 < 64 ? 64 : (rt / 2 > max_blk ? max_blk : rt / 2);
@@ -218,19 +215,36 @@ int ntt_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_fl
         if (shmem > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g.ntt_profile) {   // bracket the launch with events on its own stream (zk_ntt_profile_read sums them)
+            while (dc.ntt_ev_pool.size() < dc.ntt_ev_used + 2) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                dc.ntt_ev_pool.push_back(e);
+            }
+            e0 = dc.ntt_ev_pool[dc.ntt_ev_used++];
+            e1 = dc.ntt_ev_pool[dc.ntt_ev_used++];
+            HIP_TRY(hipEventRecord(e0, st));
+        }
         ZK_LAUNCH((ntt_pass_kernel<F>), (unsigned)tiles, blk, shmem, st, src, dst, tw, A, scale, tpre, tpost);
+        if (e1) HIP_TRY(hipEventRecord(e1, st));
         HIP_TRY(hipGetLastError());
         log_m += plan.rd[p];
+    }
+    if (g.ntt_profile) {
+        dc.ntt_transforms++;
+        const double n_in = (in_log > 0 && in_log < logn) ? (double)(1ull << in_log) : (double)(1ull << logn);
+        dc.ntt_alg_bytes += sizeof(Fe<F>) * (n_in + (double)(1ull << logn));
     }
     return ZK_OK;
 }
 
 template <class F>
-int coset_run(int field, Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st) {
+int coset_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st) {
     if (logn > 30) return ZK_ERR_INVALID_ARG;
     const uint64_t count = 1ull << logn;
     PowTables<F> t;
-    ZK_TRY(pow_tables<F>(gshift, logn, field, st, &t));
+    ZK_TRY(pow_tables<F>(dc, gshift, logn, field, st, &t));
     uint64_t blocks = (count + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     ZK_LAUNCH((coset_mul_kernel<F>), (unsigned)blocks, 256, 0, st, a, t, count);
@@ -248,12 +262,26 @@ int vec_op_run(Fe<F>* a, const Fe<F>* b, const Fe<F>* c, uint64_t n, int op, con
     return ZK_OK;
 }
 
+template <class F>
+int scale_periodic_run(Fe<F>* a, uint64_t n, const Fe<F>* table_host, uint32_t m, hipStream_t st) {
+    if (n == 0) return ZK_OK;
+    if (m == 0 || m > 16 || (m & (m - 1)) != 0) return ZK_ERR_INVALID_ARG;
+    PeriodicTable<F> t;
+    memset(&t, 0, sizeof t);
+    for (uint32_t i = 0; i < m; i++) t.v[i] = table_host[i];
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ZK_LAUNCH((scale_periodic_kernel<F>), (unsigned)blocks, 256, 0, st, a, n, t, m);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
 // ark-groth16 0.3 r1cs_to_qap.rs  R1CStoQAP::witness_map, from the point where a, b, c hold the evaluations
 // <A_i,z>, <B_i,z>, <C_i,z> on the size-m domain: seven NTTs and the pointwise glue, all in HBM.
 //   ifft(a); ifft(b); coset_fft(a); coset_fft(b); ifft(c); coset_fft(c);
 //   ab = a.b - c;  ab *= 1/Z_H(g);  coset_ifft(ab)            -> `a` holds h (m coefficients, Montgomery)
 template <class F>
-int witness_map_run(int field, Fe<F>* a, Fe<F>* b, Fe<F>* c, uint32_t logm, hipStream_t st) {
+int witness_map_run(DeviceCtx& dc, int field, Fe<F>* a, Fe<F>* b, Fe<F>* c, uint32_t logm, hipStream_t st) {
     if (logm > (uint32_t)F::TWO_ADICITY || logm > 30) return ZK_ERR_INVALID_ARG;
     const uint64_t m = 1ull << logm;
     Fe<F> w, winv, gen, ginv, zinv, one;
@@ -272,11 +300,11 @@ int witness_map_run(int field, Fe<F>* a, Fe<F>* b, Fe<F>* c, uint32_t logm, hipS
     fe_inv(zinv, gm);
     Fe<F>* vs[3] = {a, b, c};
     for (int k = 0; k < 3; k++) {
-        ZK_TRY(ntt_run<F>(field, vs[k], logm, winv, 1, st, nullptr, nullptr));   // ifft_in_place
-        ZK_TRY(ntt_run<F>(field, vs[k], logm, w, 0, st, &gen, nullptr));          // coset_fft = distribute_powers(g) ; fft (fused)
+        ZK_TRY(ntt_run<F>(dc, field, vs[k], logm, winv, 1, st, nullptr, nullptr));   // ifft_in_place
+        ZK_TRY(ntt_run<F>(dc, field, vs[k], logm, w, 0, st, &gen, nullptr));          // coset_fft = distribute_powers(g) ; fft (fused)
     }
     ZK_TRY(vec_op_run<F>(a, b, c, m, VEC_QAP, zinv, st));
-    ZK_TRY(ntt_run<F>(field, a, logm, winv, 1, st, nullptr, &ginv));             // coset_ifft = ifft ; distribute_powers(g^-1) (fused)
+    ZK_TRY(ntt_run<F>(dc, field, a, logm, winv, 1, st, nullptr, &ginv));             // coset_ifft = ifft ; distribute_powers(g^-1) (fused)
     return ZK_OK;
 }
 }  // namespace zk

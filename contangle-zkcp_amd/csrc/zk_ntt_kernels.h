@@ -107,6 +107,29 @@ __global__ void __launch_bounds__(256) vec_op_kernel(Fe<F>* __restrict__ a, cons
     }
 }
 
+// a[i] *= t[i mod m], m a power of two <= 16: halo2_proofs 0.2 EvaluationDomain::divide_by_vanishing_poly -- on the extended
+// coset X^n - 1 takes only 2^(extended_k - k) distinct values, `t_evaluations` holds their inverses (poly/domain.rs)
+template <class F>
+struct PeriodicTable {
+    Fe<F> v[16];
+};
+template <class F>
+__global__ void __launch_bounds__(256) scale_periodic_kernel(Fe<F>* __restrict__ a, uint64_t n, PeriodicTable<F> t, uint32_t m) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<F> x = a[i], w;
+        const uint32_t j = (uint32_t)i & (m - 1);
+        ZK_UNROLL
+        for (int l = 0; l < F::N; l++) {
+            uint32_t v = 0;
+            ZK_UNROLL
+            for (uint32_t q = 0; q < 16; q++) v = (j == q) ? t.v[q].v[l] : v;   // the table is a kernel argument (SGPRs): select, do not index
+            w.v[l] = v;
+        }
+        fe_mul(x, x, w);
+        a[i] = x;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NTT: mixed-radix decimation-in-frequency, one kernel per pass, natural order in and out.
 //

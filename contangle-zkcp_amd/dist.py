@@ -1,46 +1,109 @@
-"""Multi-GPU MSM: one process per GPU, window-range sharding, one tiny collective.
+"""Multi-GPU MSM, one process per GPU: window-range sharding and one tiny collective.
 
 Rank g owns windows [W*g/G, W*(g+1)/G) of the signed-digit decomposition; every
 rank holds all bases (the SRS is uploaded once per GPU) and all scalars.  Each rank returns
 sum_{w in range} 2^(c*w) T_w as one Jacobian point; EC addition is not an RCCL reduction op, so
-the "reduce" is an all_gather of 3*limbs u64 words per rank (96 B; 144 B for BLS12-381 G1)
-followed by <= G-1 point additions on every rank.  NTT stays single-GPU (north_star).
+the "reduce" is an all_gather of 3*limbs u64 words per rank and MSM (96 B; 144 B for BLS12-381 G1)
+followed by <= G-1 point additions on every rank.  MSMs that are issued together (the column
+commitments of a halo2 proof, the five MSMs of a Groth16 proof) share ONE all_gather.
+NTT stays single-GPU (north_star).
+
+(The other multi-GPU form -- one process driving several GPUs through zk_init_devices, the
+fan-out and the additions inside the C ABI -- needs none of this: see include/zkcp_amd.h.)
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import msm, msm_window_count, point_add
+from . import base_limbs, msm, msm_batch, msm_submit, msm_window_count, point_add
 
 
 def window_range(n_windows, rank, world):
     return n_windows * rank // world, n_windows * (rank + 1) // world
 
 
-def msm_sharded(bases, scalars, montgomery=False, window_bits=0, group=None, stream=0):
-    """All ranks call with the same bases/scalars; returns the full Jacobian sum on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    n = int(scalars.shape[0])
-    nwin = msm_window_count(bases.curve, n, window_bits)
-    lo, hi = window_range(nwin, rank, world)
-    part = msm(bases, scalars, montgomery=montgomery, window_bits=window_bits, windows=(lo, hi), stream=stream) \
-        if hi > lo else _identity(part_len=None, bases=bases)
+def _world(group):
+    if not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def _identity(curve):
+    return np.zeros(3 * base_limbs(curve), dtype=np.uint64)
+
+
+def _gather_add(curves, parts, group):
+    """parts: this rank's Jacobian partial sums, one per MSM (curves[i] names the curve of parts[i]); one all_gather of
+    the concatenation, then every rank adds the G partials of every MSM"""
+    world, _ = _world(group)
     if world == 1:
-        return part
-    backend = dist.get_backend(group)
-    t = torch.from_numpy(part.view(np.int64).copy())
-    if backend == "nccl":
+        return parts
+    flat = np.concatenate([np.ascontiguousarray(p, dtype=np.uint64).ravel() for p in parts])
+    t = torch.from_numpy(flat.view(np.int64).copy())
+    if dist.get_backend(group) == "nccl":
         t = t.cuda()
     outs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(outs, t, group=group)
-    acc = None
-    for o in outs:
-        p = o.cpu().numpy().view(np.uint64)
-        acc = p if acc is None else point_add(bases.curve, acc, p)
-    return acc
+    host = [o.cpu().numpy().view(np.uint64) for o in outs]
+    res, off = [], 0
+    for c, p in zip(curves, parts):
+        ln = p.size
+        acc = None
+        for h in host:
+            q = h[off:off + ln]
+            acc = q.copy() if acc is None else point_add(c, acc, q)
+        res.append(acc)
+        off += ln
+    return res
 
 
-def _identity(part_len, bases):
-    from . import base_limbs
-    return np.zeros(3 * base_limbs(bases.curve), dtype=np.uint64)
+def msm_sharded(bases, scalars, montgomery=False, window_bits=0, group=None, stream=0):
+    """All ranks call with the same bases/scalars; returns the full Jacobian sum on every rank."""
+    world, rank = _world(group)
+    n = int(scalars.shape[0])
+    lo, hi = window_range(msm_window_count(bases.curve, n, window_bits), rank, world)
+    if world == 1:
+        return msm(bases, scalars, montgomery=montgomery, window_bits=window_bits, stream=stream)
+    part = msm(bases, scalars, montgomery=montgomery, window_bits=window_bits, windows=(lo, hi), stream=stream) \
+        if hi > lo else _identity(bases.curve)
+    return _gather_add([bases.curve], [part], group)[0]
+
+
+def msm_batch_sharded(bases, d_cols, montgomery=False, window_bits=0, group=None, stream=0):
+    """count MSMs over the same bases (d_cols: device buffer [count, n, 4]); returns [count, 3 * limbs] on every rank.
+    One batched device call per rank and one all_gather for all columns."""
+    world, rank = _world(group)
+    count, n = int(d_cols.shape[0]), int(d_cols.shape[1])
+    if world == 1:
+        return msm_batch(bases, d_cols, montgomery=montgomery, window_bits=window_bits, stream=stream)
+    lo, hi = window_range(msm_window_count(bases.curve, n, window_bits), rank, world)
+    if hi > lo:
+        parts = msm_batch(bases, d_cols, montgomery=montgomery, window_bits=window_bits, windows=(lo, hi), stream=stream)
+    else:
+        parts = np.stack([_identity(bases.curve)] * count)
+    return np.stack(_gather_add([bases.curve] * count, list(parts), group))
+
+
+def msm_many_sharded(jobs, window_bits=0, group=None, stream=0):
+    """jobs: [(bases, device scalars, montgomery)] with different bases (the five MSMs of a Groth16 proof): every MSM is
+    submitted before the first is collected (deferred results), then one all_gather combines the ranks' partials"""
+    world, rank = _world(group)
+    tickets, curves = [], []
+    for bases, sc, mont in jobs:
+        n = int(sc.shape[0])
+        lo, hi = window_range(msm_window_count(bases.curve, n, window_bits), rank, world)
+        curves.append(bases.curve)
+        if world > 1 and hi == lo:
+            tickets.append(None)
+            continue
+        if len([t for t in tickets if t is not None and not isinstance(t, np.ndarray)]) >= 3:   # <= 4 MSMs in flight per device
+            for i, t in enumerate(tickets):
+                if t is not None and not isinstance(t, np.ndarray):
+                    tickets[i] = t.collect()
+                    break
+        tickets.append(msm_submit(bases, sc, montgomery=mont, window_bits=window_bits, windows=(lo, hi) if world > 1 else None,
+                                  stream=stream))
+    parts = []
+    for c, t in zip(curves, tickets):
+        parts.append(_identity(c) if t is None else (t if isinstance(t, np.ndarray) else t.collect()))
+    return _gather_add(curves, parts, group)

@@ -24,9 +24,14 @@
  *   - results are Jacobian (X, Y, Z), identity has Z = 0 -- the in-memory form of ark-ec 0.3
  *     `GroupProjective` and pasta_curves 0.4 `Ep`/`Eq`;
  *   - every function returns 0 on success or a negative zk_status; nothing throws or aborts;
- *   - thread-safe: calls are serialised per process on an internal mutex; one process drives
- *     one GPU (multi-GPU = one process per GPU, see zk_msm_opts.window_begin/window_end);
- *   - "device" pointers must be 16-byte aligned HBM addresses of the current device.
+ *   - thread-safe: any host thread may call any entry point (each call binds the calling thread to the device it
+ *     uses; host-side enqueue is serialised per device).  Asynchronous (*_device) calls on DIFFERENT streams do
+ *     not share scratch: every stream gets its own NTT ping-pong buffer / fixed-base table, every MSM in flight
+ *     its own workspaces;
+ *   - multi-GPU, two ways: (a) one process drives n GPUs (zk_init_devices): bases are uploaded to every device
+ *     and zk_msm / zk_msm_device split the scalar windows over them and add the partial sums on the host;
+ *     (b) one process per GPU (zk_init) with zk_msm_opts.window_begin/window_end and the caller's own collective;
+ *   - "device" pointers must be 16-byte aligned HBM addresses.
  *   - There is no CPU fallback: without a usable MI355X every compute entry point fails with
  *     ZK_ERR_NO_DEVICE.
  */
@@ -63,16 +68,32 @@ typedef enum {
     ZK_ERR_HIP = -4,
     ZK_ERR_OOM = -5,
     ZK_ERR_UNSUPPORTED = -6,
-    ZK_ERR_BAD_HANDLE = -7
+    ZK_ERR_BAD_HANDLE = -7,
+    ZK_ERR_BUSY = -8          /* 4 MSMs are already in flight on the device: collect one first */
 } zk_status;
 
 /* MSM tuning / sharding.  Zero-initialise for defaults. */
 typedef struct {
     int window_bits;    /* c; 0 = choose from n */
     int window_begin;   /* this call sums windows [window_begin, window_end) of the signed-digit      */
-    int window_end;     /*   decomposition, already weighted by 2^(c*w); 0,0 = all windows (one GPU) */
-    int reserved;
+    int window_end;     /*   decomposition, already weighted by 2^(c*w); 0,0 = all windows           */
+    int limb_bits;      /* bucket arithmetic: 0 = default (lazy 29/28-bit limbs), 32 = saturated 32-bit words (A/B, tests) */
+    int split_log_plus1;/* 0 = automatic; k + 1 cuts every bucket's entry list into 2^k pieces (k <= 4) */
+    int slice_len;      /* buckets per lane of the bucket reduction; 0 = automatic */
+    int big_threshold;  /* buckets longer than this take the cooperative segment path; 0 = 2 x mean + 64 */
+    int waves_per_simd; /* accumulate-kernel waves launched per SIMD; 0 = what the kernel was compiled for */
+    int flags;          /* ZK_MSM_FLAG_* */
+    int reserved[3];
 } zk_msm_opts;
+#define ZK_MSM_FLAG_NO_HOT_HELP 1   /* skewed witnesses: leave hot regions to their own sort workgroup */
+
+/* NTT plan knobs (process-wide, zk_ntt_configure).  Zero-initialise for defaults. */
+typedef struct {
+    int max_log_radix;   /* bits per pass, 1..10; 0 = 10 */
+    int log_tile_plus1;  /* 0 = automatic (log2 T = 2); k + 1 forces log2 T = k (k <= 4) */
+    int block;           /* lanes per tile workgroup: 64..1024; 0 = 512 */
+    int reserved;
+} zk_ntt_opts;
 
 /* Wall-clock of the phases of the last zk_msm* call on this process (milliseconds, HIP events).
  * The sort has three phases: digits_ms = digit counts per (scalar block, window, bucket range) + their scans,
@@ -81,11 +102,34 @@ typedef struct {
     float digits_ms, hist_ms, scatter_ms, accumulate_ms, reduce_ms, host_tail_ms, total_ms;
     int window_bits, windows_total, windows_done;
     int groups;      /* always 1 (a two-stream window-group pipeline was measured slower and removed) */
-    int limb_bits;   /* bucket arithmetic of the call: 32 = saturated words (G2), 29 = lazy unsaturated limbs (G1: 9 x 29 bits, BLS12-381 14 x 28) */
+    int limb_bits;   /* bucket arithmetic of the call: 29 = lazy unsaturated limbs (9 x 29 bits; BLS12-381 14 x 28; pairs of those on G2), 32 = saturated words */
+    float accumulate_kernel_ms;   /* msm_accumulate_kernel alone (accumulate_ms also covers the piece / segment combine kernels) */
+    int reserved;
 } zk_msm_profile;
 
+/* Sums over every MSM collected since the last reset (HIP events on the launch streams): what a bench needs when MSMs
+ * run in batches / in flight.  algorithmic_bytes = n x (32 + affine point bytes) x (windows done / windows) per MSM. */
+typedef struct {
+    uint64_t msms;
+    double accumulate_kernel_ms, accumulate_ms, sort_ms, reduce_ms, host_tail_ms, device_ms;
+    double algorithmic_bytes;
+} zk_msm_totals;
+
+/* NTT pass-kernel timing (off by default): when enabled, every ntt_pass_kernel launch is bracketed by HIP events on its
+ * stream; zk_ntt_profile_read waits for them, sums and resets.  algorithmic_bytes = 32 B x (elements read + written) per
+ * transform, whatever the number of passes. */
+typedef struct {
+    uint64_t transforms, launches;
+    double kernel_ms;
+    double algorithmic_bytes;
+} zk_ntt_totals;
+
 /* ---- lifecycle ---- */
-int zk_init(int device_id);            /* binds this process to one GPU; idempotent for the same id */
+int zk_init(int device_id);            /* this process drives one GPU; idempotent for the same id */
+/* this process drives n GPUs: per device a context, library streams and workspaces.  Device 0 of the list is
+ * the "home" device of NTTs and of device pointers whose owner cannot be determined. */
+int zk_init_devices(int n_devices, const int *device_ids);
+int zk_device_count(void);             /* devices this process drives (0 before zk_init*) */
 int zk_shutdown(void);                 /* frees every device allocation made by the library */
 const char *zk_strerror(int status);
 int zk_backend_info(char *buf, uint64_t buflen); /* e.g. "hip gfx950 AMD Instinct MI355X cu=256" */
@@ -110,7 +154,27 @@ int zk_msm(zk_curve_t c, uint64_t bases_handle, const void *scalars_host, uint64
 int zk_msm_device(zk_curve_t c, uint64_t bases_handle, const void *scalars_dev, uint64_t n,
                   int scalars_are_montgomery, const zk_msm_opts *opts, void *out_jacobian_host,
                   void *hip_stream);
-int zk_msm_last_profile(zk_msm_profile *out);
+int zk_msm_last_profile(zk_msm_profile *out);   /* of the MSM collected last */
+int zk_msm_profile_totals(zk_msm_totals *out, int reset);
+
+/* Deferred result: zk_msm_submit enqueues all device work of one MSM on `hip_stream` and returns a ticket without
+ * synchronising; zk_msm_collect waits for that MSM's last event, finishes it on the host (Horner over the <= 16
+ * window sums) and writes the Jacobian result.  A prover issues its MSMs back to back (5 per Groth16 proof, one per
+ * committed column in halo2): submitting MSM k+1 before collecting MSM k lets the GPU run k+1's sort beside k's
+ * latency-bound bucket reduction and hides the host tail.  At most 4 MSMs in flight per device; every ticket must be
+ * collected exactly once.  Scalars must stay valid and unchanged until the ticket is collected. */
+int zk_msm_submit(zk_curve_t c, uint64_t bases_handle, const void *scalars_dev, uint64_t n, int scalars_are_montgomery,
+                  const zk_msm_opts *opts, void *hip_stream, uint64_t *ticket_out);
+int zk_msm_collect(uint64_t ticket, void *out_jacobian_host);
+
+/* `count` MSMs over the SAME bases: scalars_dev holds count vectors of n scalars, vector k at element offset
+ * k * stride_elems (stride_elems >= n); out_jacobian_host receives count results.  halo2 0.2 create_proof commits all
+ * advice / lookup / permutation columns against one `Params::g_lagrange`; Groth16's a_query and b_g1_query MSMs share
+ * the assignment instead (different bases: use submit/collect for those).  The MSMs alternate between two library
+ * streams forked from `hip_stream` and joined back into it. */
+int zk_msm_batch_device(zk_curve_t c, uint64_t bases_handle, const void *scalars_dev, uint64_t n, uint32_t count,
+                        uint64_t stride_elems, int scalars_are_montgomery, const zk_msm_opts *opts,
+                        void *out_jacobian_host, void *hip_stream);
 
 /* ---- NTT: in-place radix-2 DFT of size 2^log_n, natural order in and out ----
  * a[k] <- sum_j a[j] * omega^(jk); the caller passes omega (halo2 best_fft semantics: omega or
@@ -119,6 +183,10 @@ int zk_msm_last_profile(zk_msm_profile *out);
 int zk_ntt(zk_field_t f, void *a_mont_host, uint32_t log_n, const void *omega_mont_host, int scale_by_n_inv);
 int zk_ntt_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *omega_mont_host,
                   int scale_by_n_inv, void *hip_stream);
+
+int zk_ntt_configure(const zk_ntt_opts *opts);   /* NULL restores the defaults */
+int zk_ntt_profile_enable(int on);
+int zk_ntt_profile_read(zk_ntt_totals *out);
 
 /* The NTT fused with the coset shifts around it (either pointer may be NULL):
  *   a[i] *= g_pre^i  ->  DFT (root omega, optional 1/n scaling)  ->  a[k] *= g_post^k
@@ -149,8 +217,12 @@ int zk_coset_mul_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const vo
 int zk_vec_op_device(zk_field_t f, int op, void *a_dev, const void *b_dev, const void *c_dev, uint64_t n,
                      const void *scalar_mont_host, void *hip_stream);
 int zk_groth16_witness_map_device(zk_field_t f, void *a_dev, void *b_dev, void *c_dev, uint32_t log_m, void *hip_stream);
+/* a[i] *= table[i mod m], m a power of two <= 16, table in host memory (Montgomery):
+ * halo2_proofs 0.2 poly/domain.rs EvaluationDomain::divide_by_vanishing_poly (t_evaluations). */
+int zk_vec_scale_periodic_device(zk_field_t f, void *a_dev, uint64_t n, const void *table_mont_host, uint32_t m, void *hip_stream);
 
 /* ---- host-side helpers a shim needs around the two kernels ---- */
+int zk_field_modulus(zk_field_t f, void *p_canonical_out);                          /* 4 x u64, little-endian */
 int zk_field_root_of_unity(zk_field_t f, uint32_t log_n, void *omega_mont_out);   /* ark group_gen / halo2 omega for size 2^log_n */
 int zk_field_multiplicative_generator(zk_field_t f, void *g_mont_out);            /* ark coset shift (7 BLS12-381 Fr, 5 BN254 Fr, 5 pasta) */
 int zk_field_inverse(zk_field_t f, const void *a_mont, void *out_mont);

@@ -6,6 +6,7 @@
 #include <time.h>
 #include <ucontext.h>
 
+#include <mutex>
 #include <vector>
 
 namespace emu {
@@ -91,8 +92,12 @@ int syncthreads_count(int pred) {
     return r;
 }
 
+// one kernel at a time: the fiber scheduler and the `__shared__` statics are process-wide, and the multi-device entry
+// points of the library launch from one host thread per (emulated) device
+static std::mutex g_launch_mu;
 void launch(unsigned grid, unsigned block, size_t shmem, const std::function<void()>& body) {
     if (grid == 0 || block == 0) return;
+    std::lock_guard<std::mutex> lk(g_launch_mu);
     g_block_dim = {block, 1, 1};
     g_grid_dim = {grid, 1, 1};
     std::vector<char> smem(shmem + 64);
@@ -145,8 +150,12 @@ static double now_ms() {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
+// ZK_EMU_DEVICES=k makes the emulator report k "devices" (all of them this host's memory): the multi-device host logic
+// of the library (per-device contexts, window fan-out, partial-sum addition) is exercised by the CPU test tier
 hipError_t hipGetDeviceCount(int* n) {
-    *n = 1;
+    const char* e = getenv("ZK_EMU_DEVICES");
+    const int v = e ? atoi(e) : 1;
+    *n = v >= 1 && v <= 16 ? v : 1;
     return hipSuccess;
 }
 hipError_t hipSetDevice(int) { return hipSuccess; }
@@ -188,6 +197,9 @@ hipError_t hipEventCreate(hipEvent_t* e) {
     *e = new emuEvent{0};
     return hipSuccess;
 }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipEventDestroy(hipEvent_t e) {
     delete e;
     return hipSuccess;

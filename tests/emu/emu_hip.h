@@ -109,6 +109,10 @@ hipError_t hipDeviceSynchronize();
 hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipEventCreate(hipEvent_t* e);
+enum { hipEventDisableTiming = 2 };
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
+hipError_t hipHostFree(void* p);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t st);
 hipError_t hipEventSynchronize(hipEvent_t e);

@@ -43,49 +43,18 @@ def golden_msm_case(cname, case):
 
 
 def rand_field(name, n, seed):
-    """n uniform elements of the field, Montgomery form, uint64 [n,4] (vectorised splitmix64 + rejection)."""
-    p = pyref.FIELDS[name][0]
-    out = np.zeros((n, 4), dtype=np.uint64)
-    todo = np.arange(n)
-    ctr = np.uint64(seed)
-    top_mask = np.uint64((1 << (p.bit_length() - 192)) - 1)
-    pl = [np.uint64((p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) for i in range(4)]
-    rnd = 0
-    while todo.size:
-        m = todo.size
-        with np.errstate(over="ignore"):
-            idx = (np.arange(m * 4, dtype=np.uint64) + np.uint64(rnd * 0x1000003) * np.uint64(n * 4 + 1)
-                   + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15))
-            z = idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x632BE59BD9B4E019)
-            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-            z = z ^ (z >> np.uint64(31))
-        c = z.reshape(m, 4).copy()
-        c[:, 3] &= top_mask
-        lt = np.zeros(m, dtype=bool)
-        eq = np.ones(m, dtype=bool)
-        for i in (3, 2, 1, 0):
-            lt |= eq & (c[:, i] < pl[i])
-            eq &= c[:, i] == pl[i]
-        out[todo[lt]] = c[lt]
-        todo = todo[~lt]
-        rnd += 1
-    return out
+    """n uniform elements of the field, Montgomery form, uint64 [n,4] (the product's seeded generator, checked here against
+    the independently typed modulus of oracle/pyref.py)"""
+    from contangle_zkcp_amd import synth
+    assert synth.modulus(name) == pyref.FIELDS[name][0]
+    return synth.rand_field(name, n, seed)
 
 
 def scalars_for(curve, n, seed, realistic=False):
     """canonical scalars [n,4] in [0, r); `realistic` = 40% zeros, 25% ones, 10% < 2^8."""
-    sf = pyref.CURVES[curve][1]
-    s = rand_field(sf, n, seed)   # uniform in [0, r): read as canonical integers
-    if realistic:
-        u = rand_field(sf, n, seed + 1)[:, 0] % np.uint64(100)
-        z, o, sm = u < 40, (u >= 40) & (u < 65), (u >= 65) & (u < 75)
-        s[z] = 0
-        s[o] = 0
-        s[o, 0] = 1
-        s[sm, 1:] = 0
-        s[sm, 0] &= np.uint64(0xFF)
-    return s
+    from contangle_zkcp_amd import synth
+    assert synth.CURVE_SCALAR_FIELD[curve] == pyref.CURVES[curve][1]
+    return synth.scalars_for(curve, n, seed, realistic)
 
 
 _bases_cache = {}
@@ -166,16 +135,12 @@ def check_msm_vs_oracle(zk, cname, n, window_bits=0, realistic=False, seed=5, th
     got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
     assert (got == exp).all(), (cname, n, window_bits, realistic)
     assert orc.on_curve(cname, got)
-    lazy = True   # buckets run on lazy limbs (9 x 29 bits; 14 x 28 for BLS12-381; pairs of those on the G2 twists)
-    assert zk.msm_last_profile()["limb_bits"] == (29 if lazy and os.environ.get("ZK_MSM_F29") != "0" else 32)
-    if lazy:                                                  # and must agree with the saturated 32-bit path
-        os.environ["ZK_MSM_F29"] = "0"
-        try:
-            got32 = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
-            assert zk.msm_last_profile()["limb_bits"] == 32
-        finally:
-            os.environ.pop("ZK_MSM_F29")
-        assert (got32 == exp).all()
+    # buckets run on lazy limbs (9 x 29 bits; 14 x 28 for BLS12-381; pairs of those on the G2 twists) ...
+    assert zk.msm_last_profile()["limb_bits"] == 29
+    # ... and must agree with the saturated 32-bit path (zk_msm_opts.limb_bits = 32)
+    got32 = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits, limb_bits=32))
+    assert zk.msm_last_profile()["limb_bits"] == 32
+    assert (got32 == exp).all()
     # halo2 entry: Montgomery scalars
     got = affine_of(zk, cname, zk.halo2.best_multiexp(orc.to_mont(sf, sc), bases))
     assert (got == exp).all(), (cname, n, "montgomery scalars")
@@ -325,13 +290,9 @@ def check_msm_slice_lengths(zk, cname, n, window_bits):
     sc = scalars_for(cname, n, 23)
     exp = orc.msm_ark(cname, pts, sc, threads=8)
     bases = zk.Bases(cname, pts)
-    try:
-        for L in (1, 2, 3, 8, 64, 1024):
-            os.environ["ZK_MSM_SLICE"] = str(L)
-            got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
-            assert (got == exp).all(), (cname, L)
-    finally:
-        os.environ.pop("ZK_MSM_SLICE", None)
+    for L in (1, 2, 3, 8, 64, 1024):
+        got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits, slice_len=L))
+        assert (got == exp).all(), (cname, L)
     bases.free()
 
 
@@ -409,11 +370,148 @@ def check_msm_split(zk, cname, n, window_bits, realistic=True):
     sc = scalars_for(cname, n, 43, realistic=realistic)
     exp = orc.msm_ark(cname, pts, sc, threads=8)
     bases = zk.Bases(cname, pts)
-    try:
-        for k in (0, 1, 2, 3):
-            os.environ["ZK_MSM_SPLIT"] = str(k)
-            got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits))
-            assert (got == exp).all(), (cname, n, k)
-    finally:
-        os.environ.pop("ZK_MSM_SPLIT", None)
+    for k in (0, 1, 2, 3):
+        got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits, split_log=k))
+        assert (got == exp).all(), (cname, n, k)
     bases.free()
+
+
+# ------------------------------------------------------------------ deferred results, batches, several devices
+def check_msm_async(zk, cname, n, window_bits=0):
+    """zk_msm_submit / zk_msm_collect: three MSMs in flight over the same bases, collected out of order; a fifth
+    submission without a collect is refused with ZK_ERR_BUSY, not queued"""
+    sf = pyref.CURVES[cname][1]
+    pts = bases_for(cname, n)
+    bases = zk.Bases(cname, pts)
+    scs = [scalars_for(cname, n, 300 + i, realistic=(i == 1)) for i in range(3)]
+    exp = [orc.msm_ark(cname, pts, s, threads=8) for s in scs]
+    d = [to_device(zk, s) for s in scs[:2]] + [to_device(zk, orc.to_mont(sf, scs[2]))]
+    tk = [zk.msm_submit(bases, d[0], window_bits=window_bits), zk.msm_submit(bases, d[1], window_bits=window_bits),
+          zk.msm_submit(bases, d[2], montgomery=True, window_bits=window_bits)]
+    for i in (2, 0, 1):
+        assert (affine_of(zk, cname, tk[i].collect()) == exp[i]).all(), (cname, n, i)
+    tk = [zk.msm_submit(bases, d[0]) for _ in range(4)]
+    try:
+        zk.msm_submit(bases, d[0])
+        raise AssertionError("a fifth MSM in flight must be refused")
+    except zk.ZkError as e:
+        assert e.status == -8
+    for t in tk:
+        assert (affine_of(zk, cname, t.collect()) == exp[0]).all()
+    try:
+        tk[0].collect()
+        raise AssertionError("a ticket can be collected once")
+    except zk.ZkError as e:
+        assert e.status == -7
+    bases.free()
+
+
+def check_msm_batch(zk, cname, n, count, window_bits=0):
+    """zk_msm_batch_device: `count` scalar vectors against one bases handle (halo2's column commitments)"""
+    sf = pyref.CURVES[cname][1]
+    pts = bases_for(cname, n)
+    bases = zk.Bases(cname, pts)
+    cols = np.stack([scalars_for(cname, n, 500 + i, realistic=(i % 2 == 1)) for i in range(count)])
+    exp = [orc.msm_ark(cname, pts, cols[i], threads=8) for i in range(count)]
+    got = zk.msm_batch(bases, to_device(zk, cols), window_bits=window_bits)
+    for i in range(count):
+        assert (affine_of(zk, cname, got[i]) == exp[i]).all(), (cname, n, i)
+    mont = np.stack([orc.to_mont(sf, cols[i]) for i in range(count)])
+    got = zk.msm_batch(bases, to_device(zk, mont), montgomery=True, window_bits=window_bits)
+    for i in range(count):
+        assert (affine_of(zk, cname, got[i]) == exp[i]).all(), (cname, n, i, "montgomery")
+    bases.free()
+
+
+def check_multi_device(zk, ndev):
+    """one process, several devices (zk_init_devices): every whole MSM is split over the devices by scalar window and
+    the partial sums are added on the host; host-pointer and device-pointer entries, more devices than windows, an
+    explicit window range (stays on the home device), batches and deferred results on a multi-device process"""
+    assert zk.device_count() == ndev
+    for cname, n, wb in (("Vesta", 700, 0), ("Bls381G1", 300, 7), ("Bn254G2", 90, 5), ("Pallas", 50, 16)):
+        pts = bases_for(cname, n)
+        sc = scalars_for(cname, n, 71, realistic=True)
+        exp = orc.msm_ark(cname, pts, sc, threads=8)
+        bases = zk.Bases(cname, pts)
+        assert (affine_of(zk, cname, zk.msm(bases, sc, window_bits=wb)) == exp).all(), (cname, "host scalars")
+        assert (affine_of(zk, cname, zk.msm(bases, to_device(zk, sc), window_bits=wb)) == exp).all(), (cname, "device scalars")
+        W = zk.msm_window_count(cname, n, wb)
+        lo = zk.msm(bases, sc, window_bits=wb, windows=(0, W // 2))
+        hi = zk.msm(bases, sc, window_bits=wb, windows=(W // 2, W))
+        assert (affine_of(zk, cname, zk.point_add(cname, lo, hi)) == exp).all()
+        assert (affine_of(zk, cname, zk.msm_submit(bases, to_device(zk, sc), window_bits=wb).collect()) == exp).all()
+        bases.free()
+        adopted = zk.Bases(cname, device_tensor=to_device(zk, pts), n=n)      # resident on one device, copied to its peers
+        assert (affine_of(zk, cname, zk.msm(adopted, sc, window_bits=wb)) == exp).all(), (cname, "adopted bases")
+        adopted.free()
+    check_msm_batch(zk, "Vesta", 400, 3)
+    check_msm_edges(zk, "Bn254G1")
+    check_ntt_vs_oracle(zk, "PallasFp", 9)
+
+
+# ------------------------------------------------------------------ halo2 EvaluationDomain (poly/domain.rs)
+PASTA_ZETA = {   # pasta_curves 0.4 FieldExt::ZETA (SURVEY.md Appendix A: 5^((p-1)/3))
+    "PallasFp": 0x2d33357cb532458ed3552a23a8554e5005270d29d19fc7d27b7fd22f0201b547,
+    "PallasFq": 0x06819a58283e528e511db4d81cf70f5a0fed467d47c033af2aa9d2e050aa0e4f,
+}
+
+
+def _fe_mul_rows(name, a, consts):
+    """a[i] * consts[i mod len(consts)] elementwise through the oracle's field multiplication"""
+    out = a.copy()
+    m = len(consts)
+    for i in range(a.shape[0]):
+        if consts[i % m] is not None:
+            out[i] = orc.fe_op(name, "mul", a[i], consts[i % m])
+    return out
+
+
+def check_halo2_domain(zk, name, k, j=9):
+    """zk.halo2.EvaluationDomain against a restatement of halo2_proofs 0.2 poly/domain.rs built from the oracle's best_fft and
+    field multiplication: constants (omega, extended_k, ZETA, t_evaluations), lagrange_to_coeff, coeff_to_extended (zero
+    extension + distribute_powers_zeta: a[i] *= ZETA^(i mod 3)), extended_to_coeff, divide_by_vanishing_poly"""
+    p = pyref.FIELDS[name][0]
+    dom = zk.halo2.EvaluationDomain(name, j, k)
+    n, ek = 1 << k, dom.extended_k
+    ne = 1 << ek
+    assert ne >= n * (j - 1) and (ne >> 1) < n * (j - 1)
+    mont = lambda v: orc.int_to_limbs(pyref.mont(name, v % p), 4)
+    unmont = lambda a: orc.limbs_to_int(orc.from_mont(name, a.reshape(1, 4))[0])
+    zeta = unmont(dom.g_coset)
+    assert zeta != 1 and pow(zeta, 3, p) == 1
+    if name in PASTA_ZETA:
+        assert zeta == PASTA_ZETA[name]
+    assert (dom.omega == orc.root_of_unity(name, k)).all() and (dom.extended_omega == orc.root_of_unity(name, ek)).all()
+    w_ext = unmont(dom.extended_omega)
+    t_exp = [pow((pow(zeta * pow(w_ext, i, p) % p, n, p) - 1) % p, -1, p) for i in range(1 << (ek - k))]
+    assert all(unmont(dom.t_evaluations[i]) == t_exp[i] for i in range(len(t_exp)))
+    a = rand_field(name, n, 1234)
+    # lagrange_to_coeff: best_fft(omega^-1) then times n^-1
+    w_inv = orc.fe_op(name, "inv", dom.omega)
+    exp = _fe_mul_rows(name, orc.halo2_best_fft(name, a, w_inv, k, threads=4), [mont(pow(n, -1, p))])
+    got = to_host(zk, dom.lagrange_to_coeff(to_device(zk, a)))
+    assert (got == exp).all(), (name, k, "lagrange_to_coeff")
+    assert (to_host(zk, dom.coeff_to_lagrange(to_device(zk, got))) == a).all()
+    # coeff_to_extended
+    coeffs = got
+    padded = np.zeros((ne, 4), dtype=np.uint64)
+    padded[:n] = coeffs
+    zp = [None, mont(zeta), mont(zeta * zeta)]
+    exp_ext = orc.halo2_best_fft(name, _fe_mul_rows(name, padded, zp), dom.extended_omega, ek, threads=4)
+    dirty = padded.copy()
+    if ne > n:
+        dirty[n:] = rand_field(name, ne - n, 99)        # the padding is implied, never read
+    got_ext = to_host(zk, dom.coeff_to_extended(to_device(zk, dirty)))
+    assert (got_ext == exp_ext).all(), (name, k, "coeff_to_extended")
+    # divide_by_vanishing_poly
+    tt = [mont(v) for v in t_exp]
+    exp_div = _fe_mul_rows(name, exp_ext, tt)
+    got_div = to_host(zk, dom.divide_by_vanishing_poly(to_device(zk, exp_ext)))
+    assert (got_div == exp_div).all(), (name, k, "divide_by_vanishing_poly")
+    # extended_to_coeff: best_fft(extended_omega^-1), times 2^-extended_k, ZETA^-(i mod 3)
+    we_inv = orc.fe_op(name, "inv", dom.extended_omega)
+    back = _fe_mul_rows(name, orc.halo2_best_fft(name, exp_ext, we_inv, ek, threads=4), [mont(pow(ne, -1, p))])
+    back = _fe_mul_rows(name, back, [None, mont(zeta * zeta), mont(zeta)])
+    got_back = to_host(zk, dom.extended_to_coeff(to_device(zk, exp_ext)))
+    assert (got_back == back).all(), (name, k, "extended_to_coeff")
+    assert (got_back == padded).all()

@@ -41,8 +41,23 @@ def _worker(rank, world, port, emu_path, q):
         full = zkdist.msm_sharded(bases, sc, window_bits=wb)
         lo, hi = zkdist.window_range(zk.msm_window_count(cname, n, wb), rank, world)
         assert hi > lo
-        ok &= bool((zk.point_to_affine(cname, full) == orc.msm_ark(cname, pts, sc, threads=2)).all())
+        exp = orc.msm_ark(cname, pts, sc, threads=2)
+        ok &= bool((zk.point_to_affine(cname, full) == exp).all())
+        # the batched form (halo2's column commitments): one device call and ONE all_gather for all columns
+        cols = np.stack([sc, ps.scalars_for(cname, n, 32), ps.scalars_for(cname, n, 33, realistic=True)])
+        got = zkdist.msm_batch_sharded(bases, ps.to_device(zk, cols), window_bits=wb)
+        for i in range(3):
+            ok &= bool((zk.point_to_affine(cname, got[i]) == orc.msm_ark(cname, pts, cols[i], threads=2)).all())
+        # several MSMs over different bases (Groth16's five), submitted together, one all_gather
+        pts2 = ps.bases_for(cname, n, seed=12)
+        bases2 = zk.Bases(cname, pts2)
+        res = zkdist.msm_many_sharded([(bases, ps.to_device(zk, sc), False), (bases2, ps.to_device(zk, cols[1]), False),
+                                       (bases, ps.to_device(zk, cols[2]), False)], window_bits=wb)
+        ok &= bool((zk.point_to_affine(cname, res[0]) == exp).all())
+        ok &= bool((zk.point_to_affine(cname, res[1]) == orc.msm_ark(cname, pts2, cols[1], threads=2)).all())
+        ok &= bool((zk.point_to_affine(cname, res[2]) == orc.msm_ark(cname, pts, cols[2], threads=2)).all())
         bases.free()
+        bases2.free()
     zk.shutdown()
     dist.barrier()
     dist.destroy_process_group()

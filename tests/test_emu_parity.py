@@ -27,27 +27,33 @@ def zk():
     zk._lib = None
 
 
+@pytest.fixture
+def ntt_plan(zk):
+    """zk_ntt_configure for one test; the defaults come back afterwards"""
+    yield zk.ntt_configure
+    zk.ntt_configure()
+
+
 def test_ntt_golden(zk):
     ps.check_ntt_golden(zk)
 
 
 @pytest.mark.parametrize("max_logr,logt", [("10", "2"), ("3", "1"), ("2", "2"), ("4", "0")])
-def test_ntt_multipass(zk, monkeypatch, max_logr, logt):
+def test_ntt_multipass(zk, ntt_plan, max_logr, logt):
     # small radices force 2-, 3- and 4-pass plans at sizes the emulator handles quickly
-    monkeypatch.setenv("ZK_NTT_MAX_LOGR", max_logr)
-    monkeypatch.setenv("ZK_NTT_LOGT", logt)
+    ntt_plan(max_log_radix=int(max_logr), log_tile=int(logt))
     for name, logn in (("PallasFp", 7), ("Bls381Fr", 8), ("PallasFq", 5), ("Bn254Fr", 6), ("PallasFp", 1), ("PallasFp", 2)):
         if (logn + int(max_logr) - 1) // int(max_logr) > 4:
             continue
         ps.check_ntt_vs_oracle(zk, name, logn)
 
 
-def test_ntt_extend(zk, monkeypatch):
+def test_ntt_extend(zk, ntt_plan):
     ps.check_ntt_extend(zk, "PallasFp", 5, 8)        # one pass
     ps.check_ntt_extend(zk, "Bls381Fr", 9, 12)       # two passes
     ps.check_ntt_extend(zk, "PallasFp", 0, 6)        # a single coefficient
     ps.check_ntt_extend(zk, "PallasFq", 7, 7)        # nothing to extend
-    monkeypatch.setenv("ZK_NTT_MAX_LOGR", "3")
+    ntt_plan(max_log_radix=3)
     ps.check_ntt_extend(zk, "Bn254Fr", 4, 8)         # three passes
 
 
@@ -56,10 +62,9 @@ def test_ntt_two_pass_default_plan(zk):
 
 
 @pytest.mark.parametrize("block,logt", [("64", "2"), ("64", "4"), ("128", "3")])
-def test_ntt_butterflies_per_lane(zk, monkeypatch, block, logt):
+def test_ntt_butterflies_per_lane(zk, ntt_plan, block, logt):
     # 1, 2 and 8 butterflies per lane and stage
-    monkeypatch.setenv("ZK_NTT_BLOCK", block)
-    monkeypatch.setenv("ZK_NTT_LOGT", logt)
+    ntt_plan(log_tile=int(logt), block=int(block))
     ps.check_ntt_vs_oracle(zk, "PallasFp", 12)
     ps.check_ntt_vs_oracle(zk, "Bls381Fr", 11)
 
@@ -113,10 +118,10 @@ def test_msm_sort_shapes(zk):
     ps.check_msm_sort_shapes(zk, "Bls381G1", 90, (7,))
 
 
-def test_ntt_fused_coset(zk, monkeypatch):
+def test_ntt_fused_coset(zk, ntt_plan):
     for name, logn in (("Bls381Fr", 6), ("PallasFp", 11), ("Bn254Fr", 1), ("PallasFq", 12)):
         ps.check_ntt_fused_coset(zk, name, logn)
-    monkeypatch.setenv("ZK_NTT_MAX_LOGR", "3")   # three passes: pre on the first, post on the last
+    ntt_plan(max_log_radix=3)   # three passes: pre on the first, post on the last
     ps.check_ntt_fused_coset(zk, "Bls381Fr", 8)
 
 
@@ -127,3 +132,19 @@ def test_msm_bucket_splitting(zk):
     ps.check_msm_split(zk, "Bn254G2", 60, 3)
     ps.check_msm_split(zk, "Vesta", 900, 8)          # 128 buckets per range: the size-rank zones exist
     ps.check_msm_split(zk, "Bn254G1", 2500, 11)      # two ranges of 512 buckets per window
+
+
+def test_msm_deferred_results(zk):
+    ps.check_msm_async(zk, "Vesta", 300, 6)
+    ps.check_msm_async(zk, "Bls381G2", 40, 4)
+
+
+def test_msm_batch(zk):
+    ps.check_msm_batch(zk, "Pallas", 260, 5, 6)
+    ps.check_msm_batch(zk, "Bn254G1", 100, 2)
+
+
+def test_halo2_domain(zk):
+    ps.check_halo2_domain(zk, "PallasFp", 5)          # degree-9 gates: extended_k = k + 3
+    ps.check_halo2_domain(zk, "PallasFq", 4, j=5)     # extended_k = k + 2
+    ps.check_halo2_domain(zk, "PallasFp", 3, j=2)     # nothing to extend

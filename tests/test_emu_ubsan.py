@@ -17,9 +17,9 @@ lib = b.build_emu(sanitize=True)
 import contangle_zkcp_amd as zk
 import parity_suite as ps
 zk.load(path=lib); zk.init(0)
-os.environ["ZK_NTT_MAX_LOGR"] = "3"; os.environ["ZK_NTT_LOGT"] = "1"
+zk.ntt_configure(max_log_radix=3, log_tile=1)
 ps.check_ntt_vs_oracle(zk, "Bls381Fr", 7)
-os.environ.pop("ZK_NTT_MAX_LOGR"); os.environ.pop("ZK_NTT_LOGT")
+zk.ntt_configure()
 ps.check_ntt_vs_oracle(zk, "PallasFp", 11)
 ps.check_msm_vs_oracle(zk, "Vesta", 300, 6, True)
 ps.check_msm_vs_oracle(zk, "Bls381G2", 40, 4, False)

@@ -38,13 +38,15 @@ def test_ntt_vs_oracle(zk, name, logn):
 
 
 @pytest.mark.parametrize("max_logr,logt", [("3", "1"), ("5", "2"), ("7", "3")])
-def test_ntt_multipass_plans(zk, monkeypatch, max_logr, logt):
-    monkeypatch.setenv("ZK_NTT_MAX_LOGR", max_logr)
-    monkeypatch.setenv("ZK_NTT_LOGT", logt)
-    for name, logn in (("PallasFp", 12), ("Bls381Fr", 11), ("PallasFq", 9), ("Bn254Fr", 10)):
-        if (logn + int(max_logr) - 1) // int(max_logr) > 4:
-            continue
-        ps.check_ntt_vs_oracle(zk, name, logn)
+def test_ntt_multipass_plans(zk, max_logr, logt):
+    zk.ntt_configure(max_log_radix=int(max_logr), log_tile=int(logt))
+    try:
+        for name, logn in (("PallasFp", 12), ("Bls381Fr", 11), ("PallasFq", 9), ("Bn254Fr", 10)):
+            if (logn + int(max_logr) - 1) // int(max_logr) > 4:
+                continue
+            ps.check_ntt_vs_oracle(zk, name, logn)
+    finally:
+        zk.ntt_configure()
 
 
 @pytest.mark.parametrize("name,logn", [("PallasFp", 20), ("PallasFq", 20), ("Bls381Fr", 20), ("Bn254Fr", 18), ("PallasFp", 22)])
@@ -263,4 +265,177 @@ def test_msm_full_size_bls12_381(zk):
     r = pyref.FIELDS[pyref.CURVES[cname][1]][0]
     tot = sum(a * b for a, b in zip(orc.array_to_ints(sc), orc.array_to_ints(ks))) % r
     assert (got == orc.scalar_mul(cname, orc.curve_generator(cname), orc.int_to_limbs(tot, 4))).all()
+    bases.free()
+
+
+# ------------------------------------------------------------------ deferred results, batches, streams, threads
+@pytest.mark.parametrize("cname,n", [("Vesta", 1 << 16), ("Bls381G1", 5000), ("Bn254G2", 3000)])
+def test_msm_deferred_results(zk, cname, n):
+    ps.check_msm_async(zk, cname, n)
+
+
+@pytest.mark.parametrize("cname,n,count", [("Vesta", 1 << 16, 6), ("Pallas", 3000, 3), ("Bls381G2", 2000, 2)])
+def test_msm_batch(zk, cname, n, count):
+    ps.check_msm_batch(zk, cname, n, count)
+
+
+def test_ntt_two_streams_do_not_share_scratch(zk):
+    """two multi-pass NTTs (and two witness maps) enqueued on two streams run concurrently: each stream owns its
+    ping-pong buffer (the process-global scratch raced silently)"""
+    import torch
+    name, logn = "PallasFp", 18
+    n = 1 << logn
+    a, b = ps.rand_field(name, n, 61), ps.rand_field(name, n, 62)
+    w = orc.root_of_unity(name, logn)
+    exp_a = orc.halo2_best_fft(name, a, w, logn, threads=16)
+    exp_b = orc.halo2_best_fft(name, b, w, logn, threads=16)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        for _rep in range(1):
+            zk.ntt(name, da, w, stream=s1.cuda_stream)
+            zk.ntt(name, db, w, stream=s2.cuda_stream)
+        torch.cuda.synchronize()
+        assert (da.cpu().numpy().view(np.uint64) == exp_a).all()
+        assert (db.cpu().numpy().view(np.uint64) == exp_b).all()
+
+
+def test_abi_from_a_second_host_thread(zk):
+    """the caller may arrive on any host thread (rayon workers upstream): every entry point binds the thread to its
+    device first (hipSetDevice was only called in zk_init)"""
+    import threading
+    err = []
+
+    def worker():
+        try:
+            ps.check_msm_vs_oracle(zk, "Vesta", 4096, 0, True)
+            ps.check_ntt_vs_oracle(zk, "Bls381Fr", 13)
+            ps.check_witness_map(zk, "Bn254Fr", 10)
+        except BaseException as e:   # noqa: BLE001
+            err.append(e)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert not err, err
+
+
+def test_invalid_arguments_are_refused(zk):
+    """sizes are validated before anything is allocated from them (a bad log_n reached hipMalloc / a 64-bit shift)"""
+    import ctypes
+    import torch
+    lib = zk.load()
+    d = torch.zeros((16, 4), dtype=torch.int64, device="cuda")
+    w = zk.root_of_unity("Bn254Fr", 4)
+    g = zk.multiplicative_generator("Bn254Fr")
+    vp = ctypes.c_void_p
+    for bad in (29, 31, 40, 64, 200):   # Bn254Fr has two-adicity 28
+        assert lib.zk_ntt_coset_device(2, vp(d.data_ptr()), bad, zk._ptr(w), 0, zk._ptr(g), None, None) == -1
+        assert lib.zk_ntt_extend_device(2, vp(d.data_ptr()), bad, 2, zk._ptr(w), 0, zk._ptr(g), None, None) == -1
+        assert lib.zk_ntt_device(2, vp(d.data_ptr()), bad, zk._ptr(w), 0, None) == -1
+        assert lib.zk_groth16_witness_map_device(2, vp(d.data_ptr()), vp(d.data_ptr()), vp(d.data_ptr()), bad, None) == -1
+
+
+@pytest.mark.parametrize("name,k,j", [("PallasFp", 10, 9), ("PallasFq", 11, 9), ("PallasFp", 9, 5), ("Bls381Fr", 8, 3)])
+def test_halo2_domain(zk, name, k, j):
+    ps.check_halo2_domain(zk, name, k, j)
+
+
+# ------------------------------------------------------------------ BASELINE configs[2] / [3] / [4] at their full sizes
+def test_halo2_extended_domain_2p23(zk):
+    """configs[2]: halo2 0.2 EvaluationDomain on a 2^20-row circuit with a degree-9 gate set: coeff_to_extended 2^20 -> 2^23
+    (zero-extension + coset shift + NTT, three-pass plan) and extended_to_coeff at 2^23, against the oracle's restatement"""
+    import torch
+    name, k, ext = "PallasFp", 20, 23
+    n, ne = 1 << k, 1 << ext
+    coeffs = ps.rand_field(name, n, 0xE17)
+    w_ext = orc.root_of_unity(name, ext)
+    g = orc.field_generator(name)      # the coset shift; halo2's ZETA shift is covered by test_halo2_domain below
+    padded = np.zeros((ne, 4), dtype=np.uint64)
+    padded[:n] = coeffs
+    exp = orc.ark_fft(name, padded, "coset_fft", threads=os.cpu_count() or 8)
+    d = torch.empty((ne, 4), dtype=torch.int64, device="cuda")
+    d.fill_(-1)                                                   # the padding is never read
+    d[:n].copy_(torch.from_numpy(coeffs.view(np.int64)))
+    zk.halo2.coeff_to_extended(name, d, k, w_ext, g)
+    torch.cuda.synchronize()
+    got = d.cpu().numpy().view(np.uint64)
+    assert (got == exp).all()
+    # extended_to_coeff: inverse transform + coset un-shift brings the padded coefficients back
+    winv, ginv = orc.fe_op(name, "inv", w_ext), orc.fe_op(name, "inv", g)
+    zk.ntt(name, d, winv, scale_by_n_inv=True, coset_post=ginv)
+    torch.cuda.synchronize()
+    back = d.cpu().numpy().view(np.uint64)
+    assert (back == padded).all()
+    # and on a dense 2^23 vector against the oracle's coset_ifft
+    dense = ps.rand_field(name, ne, 0xE18)
+    d.copy_(torch.from_numpy(dense.view(np.int64)))
+    zk.ntt(name, d, winv, scale_by_n_inv=True, coset_post=ginv)
+    torch.cuda.synchronize()
+    assert (d.cpu().numpy().view(np.uint64) == orc.ark_fft(name, dense, "coset_ifft", threads=os.cpu_count() or 8)).all()
+
+
+def test_groth16_bn254_2p22(zk):
+    """configs[3]: BN254 Fr at the 2^22 domain: the NTT and the whole witness map (7 NTTs + glue) vs the oracle"""
+    thr = os.cpu_count() or 8
+    ps.check_ntt_vs_oracle(zk, "Bn254Fr", 22, threads=thr)
+    ps.check_ntt_fused_coset(zk, "Bn254Fr", 22, threads=thr)
+    ps.check_witness_map(zk, "Bn254Fr", 22, threads=thr)
+
+
+def _identity_msm(zk, cname, n, seed, realistic, oracle_too):
+    """MSM(s, [k_i G]) = [sum s_i k_i mod r] G at any size; bases from the windowed fixed-base path on the GPU"""
+    import torch
+    from oracle import pyref
+    ks = ps.scalars_for(cname, n, seed)
+    sc = ps.scalars_for(cname, n, seed + 1, realistic=realistic)
+    nl = zk.base_limbs(cname)
+    d_pts = torch.empty((n, 2 * nl), dtype=torch.int64, device="cuda")
+    zk.fixed_base_msm_device(cname, torch.from_numpy(ks.view(np.int64)).cuda(), d_pts, n)
+    torch.cuda.synchronize()
+    bases = zk.Bases(cname, device_tensor=d_pts, n=n)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    got = zk.point_to_affine(cname, zk.msm(bases, d_sc))
+    assert zk.msm_last_profile()["limb_bits"] == 29
+    r = pyref.FIELDS[pyref.CURVES[cname][1]][0]
+    a, b = sc.astype(object), ks.astype(object)
+    sv = a[:, 0] + (a[:, 1] << 64) + (a[:, 2] << 128) + (a[:, 3] << 192)
+    kv = b[:, 0] + (b[:, 1] << 64) + (b[:, 2] << 128) + (b[:, 3] << 192)
+    tot = int((sv * kv).sum() % r)
+    exp = orc.scalar_mul(cname, orc.curve_generator(cname), orc.int_to_limbs(tot, 4))
+    assert (got == exp).all(), (cname, n)
+    if oracle_too:
+        pts = d_pts.cpu().numpy().view(np.uint64)
+        assert (got == orc.msm_ark(cname, pts, sc, threads=min(64, os.cpu_count() or 8))).all(), (cname, n, "oracle")
+    return bases, d_sc, exp
+
+
+@pytest.mark.parametrize("cname,logn,oracle_too", [("Bn254G2", 20, True), ("Bls381G2", 20, True), ("Bn254G2", 22, False),
+                                                   ("Bls381G2", 22, False)])
+def test_msm_g2_full_size(zk, cname, logn, oracle_too):
+    """configs[3]: Groth16's b_g2_query MSM at 2^20 (the domain of the reference's largest test) and 2^22, realistic witness"""
+    bases, _, _ = _identity_msm(zk, cname, 1 << logn, 4000 + logn, True, oracle_too)
+    bases.free()
+
+
+@pytest.mark.parametrize("cname", ["Vesta", "Pallas"])
+def test_msm_pasta_2p22_window_shares(zk, cname):
+    """configs[4]: 2^22-point Pasta MSM, whole and as the 8 window shares of an 8-GPU run added up (one GPU plays all
+    ranks; the collective itself is covered by tests/test_dist_gloo.py and tests/test_multi_device_emu.py)"""
+    n = 1 << 22
+    bases, d_sc, exp = _identity_msm(zk, cname, n, 5100, False, False)
+    W = zk.msm_window_count(cname, n)
+    acc = None
+    for g in range(8):
+        lo, hi = W * g // 8, W * (g + 1) // 8
+        part = zk.msm(bases, d_sc, windows=(lo, hi))
+        acc = part if acc is None else zk.point_add(cname, acc, part)
+    assert (zk.point_to_affine(cname, acc) == exp).all()
+    bases.free()
+
+
+def test_msm_bls12_381_g1_2p22(zk):
+    """the reference's curve at configs[3]'s size"""
+    bases, _, _ = _identity_msm(zk, "Bls381G1", 1 << 22, 5200, True, False)
     bases.free()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Sweep the MSM launch knobs (env: ZK_MSM_C, ZK_MSM_SLICE, ZK_MSM_WAVES, ZK_MSM_BIG) on one GPU; prints phase times."""
+"""Sweep the MSM launch knobs (zk_msm_opts: window_bits, slice_len, waves_per_simd, split_log, big_threshold) on one GPU;
+prints phase times."""
 import itertools, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,23 +21,22 @@ torch.cuda.synchronize()
 bases = zk.Bases(curve, device_tensor=d_pts, n=n)
 d_sc = torch.from_numpy(ps.scalars_for(curve, n, 0xC0DE).view(np.int64)).cuda()
 ref = None
-grid = {"ZK_MSM_SPLIT": ["0", "1"], "ZK_MSM_C": ["16", "15"], "ZK_MSM_SLICE": ["1", "2", "4", "16"], "ZK_MSM_WAVES": ["2", "3"]}
-if os.environ.get("TUNE_GRID"):   # e.g. TUNE_GRID='{"ZK_MSM_SLICE": ["2", "4"]}'
+grid = {"split_log": [0, 1], "window_bits": [16, 15], "slice_len": [1, 2, 4, 16], "waves_per_simd": [2, 3]}
+if os.environ.get("TUNE_GRID"):   # e.g. TUNE_GRID='{"slice_len": [2, 4]}'
     import json
     grid = json.loads(os.environ["TUNE_GRID"])
-base = {"ZK_MSM_C": "16", "ZK_MSM_SLICE": "8", "ZK_MSM_WAVES": "3", "ZK_MSM_SPLIT": "1"}
+base = {"window_bits": 16, "slice_len": 8, "waves_per_simd": 3, "split_log": 1}
 configs = [dict(base)]
 for k, vals in grid.items():
     for v in vals:
         c = dict(base); c[k] = v
         if c not in configs: configs.append(c)
 for c in configs:
-    os.environ.update(c)
-    for _ in range(2): out = zk.msm(bases, d_sc)
+    for _ in range(2): out = zk.msm(bases, d_sc, **c)
     acc = {}
     R = 5
     for _ in range(R):
-        out = zk.msm(bases, d_sc)
+        out = zk.msm(bases, d_sc, **c)
         p = zk.msm_last_profile()
         for k, v in p.items(): acc[k] = acc.get(k, 0) + v / R
     aff = zk.point_to_affine(curve, out)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sweep NTT plan knobs (env: ZK_NTT_MAX_LOGR, ZK_NTT_LOGT, ZK_NTT_BLOCK) on one GPU."""
+"""Sweep NTT plan knobs (zk_ntt_configure: max_log_radix, log_tile, block) on one GPU."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ w = zk.root_of_unity(name, logn)
 ref = None
 st = torch.cuda.current_stream().cuda_stream
 for maxr, logt, blk in [(10, 2, 256), (10, 2, 512), (10, 2, 1024), (10, 1, 256), (10, 1, 512), (10, 0, 256), (7, 3, 256), (7, 4, 256), (7, 4, 512), (7, 3, 512), (8, 3, 512), (9, 2, 512)]:
-    os.environ.update({"ZK_NTT_MAX_LOGR": str(maxr), "ZK_NTT_LOGT": str(logt), "ZK_NTT_BLOCK": str(blk)})
+    zk.ntt_configure(max_log_radix=maxr, log_tile=logt, block=blk)
     d = torch.from_numpy(a.view(np.int64)).cuda()
     zk.ntt(name, d, w, stream=st); torch.cuda.synchronize()
     out = d.cpu().numpy().view(np.uint64)
