@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 passes written by tools/pmc_run.sh (kernel stats, SQ counters, FETCH_SIZE / WRITE_SIZE) into
-one text file and update profiles/traffic.json.   usage: pmc_summary.py gpurun_out/<dir> profiles/<name>.txt [title]
+one text file and update profiles/traffic.json.
+usage: pmc_summary.py gpurun_out/<dir> profiles/<name>.txt <workload key, e.g. halo2_2p20> [title]
+
+traffic.json is stamped with the hash of the kernel sources it was measured on (bench.py drops `roofline.traffic` when the
+sources have changed since) and keeps one entry per workload and hot kernel.
 
 HBM traffic follows MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in units of 32 B... (the guide: on gfx950 FETCH_SIZE
 reports kilobytes-like units of 64 B requests and HALF the bytes of wide coalesced streaming reads); the raw counter sums
@@ -13,8 +17,8 @@ def short(name):
 
 
 def main():
-    src, dst = sys.argv[1], sys.argv[2]
-    title = sys.argv[3] if len(sys.argv) > 3 else ""
+    src, dst, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+    title = sys.argv[4] if len(sys.argv) > 4 else ""
     out = [title or "rocprofv3 passes of bench.py; per-launch averages", ""]
     stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
@@ -57,18 +61,36 @@ def main():
             out.append("    HBM bytes (FETCH + WRITE, KB units)   %.4g + %.4g = %.4g" % (fb, wb, fb + wb))
             traffic[k] = fb + wb
     open(dst, "w").write("\n".join(out) + "\n")
-    acc = [v for k, v in traffic.items() if "msm_accumulate_kernel" in k and "big" not in k]
-    if acc:
-        tpath = os.path.join(os.path.dirname(dst), "traffic.json")
-        valu = [per[k]["SQ_INSTS_VALU"] / max(1, launches[(k, "pmc_sq")]) for k in per if "msm_accumulate_kernel" in k and "big" not in k]
-        json.dump({"msm_accumulate_kernel_hbm_bytes_per_launch": int(acc[0]),
-                   "msm_accumulate_kernel_valu_wave_insts_per_launch": int(valu[0]) if valu else None,
-                   "source": os.path.basename(dst),
-                   "note": "FETCH_SIZE + WRITE_SIZE (separate --pmc passes), KB per launch x 1024, uncorrected: gfx950 FETCH_SIZE "
-                           "under-counts wide coalesced streams by 2x (guide) but this kernel's reads are random gathers of 80-byte "
-                           "lazy-limb bases (uncalibrated pattern, taken at face value); the bases stay resident in the 256 MiB "
-                           "Infinity Cache and the kernel is VALU-bound (DESIGN.md section 4)",
-                   "all_kernels": {k: int(v) for k, v in traffic.items()}}, open(tpath, "w"), indent=1)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_src_sha16
+    tpath = os.path.join(os.path.dirname(dst), "traffic.json")
+    sha = kernel_src_sha16()
+    try:
+        tj = json.load(open(tpath))
+    except Exception:
+        tj = {}
+    if tj.get("kernel_src_sha16") != sha:
+        tj = {"kernel_src_sha16": sha, "workloads": {}}
+    tj["note"] = ("per launch: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (KB units x 1024).  gfx950 FETCH_SIZE reports half the "
+                  "bytes of wide coalesced streaming reads (MI355X_MICROARCH.md): doubled for ntt_pass_kernel (16-B-per-lane streams), taken at "
+                  "face value for msm_accumulate_kernel (random gathers of 80-byte records: uncalibrated pattern; Infinity-Cache hits are counted)")
+    entry = {}
+    for want, corr in (("msm_accumulate_kernel", 1.0), ("ntt_pass_kernel", 2.0)):
+        ks = [k for k in per if want in k and "big" not in k]
+        if not ks:
+            continue
+        fetch = sum(per[k].get("FETCH_SIZE", 0) for k in ks) * 1024
+        write = sum(per[k].get("WRITE_SIZE", 0) for k in ks) * 1024
+        nf = sum(launches[(k, "pmc_fetch")] for k in ks)
+        nw = sum(launches[(k, "pmc_write")] for k in ks)
+        valu = sum(per[k].get("SQ_INSTS_VALU", 0) for k in ks)
+        ns = sum(launches[(k, "pmc_sq")] for k in ks)
+        entry[want] = {"hbm_bytes_per_launch": int(corr * fetch / max(1, nf) + write / max(1, nw)),
+                       "fetch_bytes_raw_per_launch": int(fetch / max(1, nf)), "write_bytes_per_launch": int(write / max(1, nw)),
+                       "fetch_correction": corr, "valu_wave_insts_per_launch": int(valu / max(1, ns)) if ns else None,
+                       "launches_profiled": int(nf), "source": os.path.basename(dst)}
+    tj["workloads"][workload] = entry
+    json.dump(tj, open(tpath, "w"), indent=1)
     print("\n".join(out[:40]))
 
 
