@@ -36,14 +36,18 @@ HBM_PEAK_GBS = 8000.0
 NCOL = 13   # advice columns of the reference's halo2 circuit
 
 
+KERNEL_SOURCES = ("zk_field.h", "zk_field29.h", "zk_mul_asm.h", "zk_params.h", "zk_params29.h", "zk_curve.h", "zk_curve29.h",
+                  "zk_msm_kernels.h", "zk_ntt_kernels.h", "zk_msm.inl", "zk_ntt.inl")
+
+
 def kernel_src_sha16():
-    """identity of the kernel sources: profiles/traffic.json is only believed for the build it was measured on"""
+    """identity of the device code (kernels, field / curve arithmetic, launch plans): profiles/traffic.json is only
+    believed for the kernels it was measured on; host-side files (the ABI, codecs) do not enter"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "contangle-zkcp_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".inl", ".cc")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

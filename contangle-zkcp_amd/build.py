@@ -17,7 +17,7 @@ EMU_LIB = os.path.join(EMU_DIR, "libzkcp_emu.so")
 CURVES = ["Pallas", "Vesta", "Bn254G1", "Bls381G1", "Bn254G2", "Bls381G2"]
 FIELDS = ["PallasFp", "PallasFq", "Bn254Fr", "Bls381Fr"]
 # (source, extra define, object tag)
-UNITS = [("zk_api.cc", None, "api")] + \
+UNITS = [("zk_api.cc", None, "api"), ("zk_wire.cc", None, "wire")] + \
         [("zk_msm_inst.cc", "ZK_CURVE=" + c, "msm_" + c) for c in CURVES] + \
         [("zk_ntt_inst.cc", "ZK_FIELD=" + f, "ntt_" + f) for f in FIELDS]
 

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "zkcp_amd.h")).read()
+def declared_symbols(header="zkcp_amd.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", src)))
 
@@ -30,6 +30,11 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(lib, s), "missing export " + s
     assert sorted(zk.EXPORTS) == syms
+    # the prover-side header (wire formats, polynomial helpers, Groth16 glue)
+    psyms = declared_symbols("zkcp_amd_prover.h")
+    for s in psyms:
+        assert hasattr(lib, s), "missing export " + s
+    assert sorted(zk.ark_serialize.PROVER_EXPORTS + getattr(zk, "PROVER_EXPORTS", [])) == psyms
 
 
 def test_no_gpu_fails_loudly():

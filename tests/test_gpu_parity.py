@@ -439,3 +439,30 @@ def test_msm_bls12_381_g1_2p22(zk):
     """the reference's curve at configs[3]'s size"""
     bases, _, _ = _identity_msm(zk, "Bls381G1", 1 << 22, 5200, True, False)
     bases.free()
+
+
+@pytest.mark.parametrize("pairing,g1,g2", [("Bls381", "Bls381G1", "Bls381G2"), ("Bn254", "Bn254G1", "Bn254G2")])
+def test_proving_key_file_to_resident_bases(zk, pairing, g1, g2):
+    """f3 -> a8: a ProvingKey in the reference's on-disk form (serialize_unchecked, lib/src/utils.rs:85-102) is indexed, its
+    query vectors are decoded straight into resident bases handles, and MSMs over them match the oracle"""
+    az = zk.ark_serialize
+    n = 3000
+    a_q, b2_q = ps.bases_for(g1, n, seed=21), ps.bases_for(g2, n, seed=22)
+    one1, one2 = ps.bases_for(g1, 1, seed=23), ps.bases_for(g2, 1, seed=24)
+    a_q[5] = 0                                                     # an identity element inside a query vector
+    members = {"alpha_g1": one1, "beta_g2": one2, "gamma_g2": one2, "delta_g2": one2, "gamma_abc_g1": a_q[:3], "beta_g1": one1,
+               "delta_g1": one1, "a_query": a_q, "b_g1_query": a_q[::-1].copy(), "b_g2_query": b2_q, "h_query": a_q[: n - 1], "l_query": a_q[:100]}
+    buf = az.ProvingKey.serialize_unchecked(pairing, members)
+    pk = az.ProvingKey.deserialize_unchecked(pairing, buf)
+    sc = ps.scalars_for(g1, n, 77, realistic=True)
+    for name, curve, pts in (("a_query", g1, a_q), ("b_g2_query", g2, b2_q)):
+        bases = pk.upload(name)
+        assert bases.n == n
+        got = zk.point_to_affine(curve, zk.msm(bases, sc))
+        assert (got == orc.msm_ark(curve, pts, sc, threads=8)).all(), name
+        bases.free()
+    # ark-groth16 uses a_query[1..] with the witness and adds a_query[0] (the constant-one wire) separately
+    tail = pk.upload("a_query", skip_first=1)
+    got = zk.point_to_affine(g1, zk.msm(tail, sc[1:]))
+    assert (got == orc.msm_ark(g1, a_q[1:], sc[1:], threads=8)).all()
+    tail.free()
