@@ -461,4 +461,6 @@ def fixed_base_msm_device(curve, d_scalars, d_out, n, base=None, montgomery=Fals
                                            _ptr(d_out), ctypes.c_void_p(stream)), "zk_fixed_base_msm_device")
 
 
-from . import ark, ark_serialize, halo2  # noqa: E402,F401  (interface mirrors)
+from . import ark, ark_serialize, groth16, halo2  # noqa: E402,F401  (interface mirrors)
+
+PROVER_EXPORTS = groth16.PROVER_EXPORTS + halo2.PROVER_EXPORTS

@@ -5,6 +5,7 @@
 #include "zk_internal.h"
 #include "zk_msm_decl.h"
 #include "zk_ntt_decl.h"
+#include "zkcp_amd_prover.h"
 
 #include <thread>
 
@@ -51,6 +52,16 @@ int stream_scratch(DeviceCtx& dc, hipStream_t st, StreamScratch** out) {
 }  // namespace zk
 
 namespace {
+// R1CS matrices of the circuits in use (zk_r1cs_matrix_upload): fixed per circuit, resident on the home device
+std::mutex g_mat_mu;
+std::map<uint64_t, R1csMatrix> g_mats;
+uint64_t g_next_mat = 1;
+void free_matrix(R1csMatrix& m) {
+    for (void* p : {m.row_ptr, m.col, m.val, m.long_rows})
+        if (p) hipFree(p);
+    m = R1csMatrix();
+}
+
 template <class C>
 void jac_to_xyzz(XYZZ<C>& r, const Jacobian<C>& j) {
     if (fe_is_zero(j.z)) {
@@ -119,6 +130,9 @@ void free_device(DeviceCtx& dc) {
         ws_free(s->ntt_tmp);
         ws_free(s->fb_table);
         ws_free(s->fb_tmp);
+        ws_free(s->poly_a);
+        ws_free(s->poly_b);
+        ws_free(s->poly_tot);
     }
     dc.scratch.clear();
     for (auto& j : dc.jobs) free_job(j);
@@ -356,9 +370,9 @@ int init_devices_locked(int n, const int* ids) {
         dc->num_cus = prop.multiProcessorCount;
         if (i == 0) {
 #if defined(ZK_EMU)
-            snprintf(g.info, sizeof g.info, "emu %s x%d", prop.name, n);
+            snprintf(g.info, sizeof g.info, "emu %.200s x%d", prop.name, n);
 #else
-            snprintf(g.info, sizeof g.info, "hip %s %s cu=%d x%d", prop.gcnArchName, prop.name, prop.multiProcessorCount, n);
+            snprintf(g.info, sizeof g.info, "hip %.60s %.120s cu=%d x%d", prop.gcnArchName, prop.name, prop.multiProcessorCount, n);
 #endif
         }
         devs.push_back(std::move(dc));
@@ -429,6 +443,12 @@ API int zk_shutdown(void) {
         }
     g.bases.clear();
     g.tickets.clear();
+    {
+        std::lock_guard<std::mutex> lkm(g_mat_mu);
+        if (!g.devs.empty()) hipSetDevice(g.devs[0]->device);
+        for (auto& kv : g_mats) free_matrix(kv.second);
+        g_mats.clear();
+    }
     for (auto& dc : g.devs) free_device(*dc);
     g.devs.clear();
     g.inited = false;
@@ -851,6 +871,189 @@ API int zk_groth16_witness_map_device(zk_field_t f, void* a, void* b, void* c, u
     if (!a || !b || !c || !aligned16(a) || !aligned16(b) || !aligned16(c)) return ZK_ERR_INVALID_ARG;
     DEVICE_ENTRY(a);
     FIELD_SWITCH(f, return witness_map_run<F>(dc, (int)f, (Fe<F>*)a, (Fe<F>*)b, (Fe<F>*)c, log_m, (hipStream_t)stream));
+    return ZK_ERR_INVALID_ARG;
+}
+
+API int zk_r1cs_matrix_upload(zk_field_t f, const uint64_t* row_ptr, const uint32_t* col, const void* val, uint64_t n_rows, uint64_t n_cols,
+                              uint64_t* handle_out) {
+    if (!handle_out || !row_ptr || (int)f < 0 || (int)f > (int)ZK_FR_BLS12_381) return ZK_ERR_INVALID_ARG;
+    const uint64_t nnz = row_ptr[n_rows];
+    if (row_ptr[0] != 0 || (nnz && (!col || !val)) || n_cols >= (1ull << 32)) return ZK_ERR_INVALID_ARG;
+    std::vector<uint64_t> long_rows;
+    for (uint64_t i = 0; i < n_rows; i++) {
+        if (row_ptr[i + 1] < row_ptr[i]) return ZK_ERR_INVALID_ARG;
+        if (row_ptr[i + 1] - row_ptr[i] > R1CS_LONG_ROW) long_rows.push_back(i);
+    }
+    for (uint64_t k = 0; k < nnz; k++)
+        if (col[k] >= n_cols) return ZK_ERR_INVALID_ARG;   // a mat-vec must never index past the assignment
+    DEVICE_ENTRY(nullptr);
+    R1csMatrix m;
+    m.field = (int)f;
+    m.n_rows = n_rows;
+    m.n_cols = n_cols;
+    m.nnz = nnz;
+    m.n_long = long_rows.size();
+    auto put = [&](void** dst, const void* src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(dst, bytes ? bytes : 16));
+        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return ZK_OK;
+    };
+    int st = put(&m.row_ptr, row_ptr, (n_rows + 1) * 8);
+    if (st == ZK_OK) st = put(&m.col, col, nnz * 4);
+    if (st == ZK_OK) st = put(&m.val, val, nnz * 32);
+    if (st == ZK_OK) st = put(&m.long_rows, long_rows.data(), long_rows.size() * 8);
+    if (st != ZK_OK) {
+        free_matrix(m);
+        return st;
+    }
+    std::lock_guard<std::mutex> lkm(g_mat_mu);
+    const uint64_t h = g_next_mat++;
+    g_mats[h] = m;
+    *handle_out = h;
+    return ZK_OK;
+}
+API int zk_r1cs_matrix_free(uint64_t handle) {
+    DEVICE_ENTRY(nullptr);
+    std::lock_guard<std::mutex> lkm(g_mat_mu);
+    auto it = g_mats.find(handle);
+    if (it == g_mats.end()) return ZK_ERR_BAD_HANDLE;
+    hipDeviceSynchronize();
+    free_matrix(it->second);
+    g_mats.erase(it);
+    return ZK_OK;
+}
+static int find_matrix(uint64_t handle, R1csMatrix* out) {
+    std::lock_guard<std::mutex> lkm(g_mat_mu);
+    auto it = g_mats.find(handle);
+    if (it == g_mats.end()) return ZK_ERR_BAD_HANDLE;
+    *out = it->second;
+    return ZK_OK;
+}
+API int zk_r1cs_matvec_device(uint64_t matrix, const void* z, void* out, uint64_t out_len, void* stream) {
+    if (!z || !out || !aligned16(z) || !aligned16(out)) return ZK_ERR_INVALID_ARG;
+    R1csMatrix m;
+    ZK_TRY(find_matrix(matrix, &m));
+    DEVICE_ENTRY(nullptr);
+    FIELD_SWITCH((zk_field_t)m.field, return r1cs_matvec_run<F>(m, (const Fe<F>*)z, (Fe<F>*)out, out_len, (hipStream_t)stream));
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_groth16_witness_map_r1cs_device(zk_field_t f, uint64_t ha, uint64_t hb, uint64_t hc, const void* z, uint64_t num_inputs,
+                                           uint32_t log_m, void* a, void* b, void* c, void* stream) {
+    if (!z || !a || !b || !c || !aligned16(z) || !aligned16(a) || !aligned16(b) || !aligned16(c) || log_m > 30) return ZK_ERR_INVALID_ARG;
+    R1csMatrix ma, mb, mc;
+    ZK_TRY(find_matrix(ha, &ma));
+    ZK_TRY(find_matrix(hb, &mb));
+    ZK_TRY(find_matrix(hc, &mc));
+    const uint64_t m = 1ull << log_m, nc = ma.n_rows;
+    if (ma.field != (int)f || mb.field != (int)f || mc.field != (int)f || mb.n_rows != nc || mc.n_rows != nc || nc + num_inputs > m ||
+        num_inputs > ma.n_cols)
+        return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(nullptr);
+    FIELD_SWITCH(f, {
+        hipStream_t st = (hipStream_t)stream;
+        ZK_TRY(r1cs_matvec_run<F>(ma, (const Fe<F>*)z, (Fe<F>*)a, m, st));
+        ZK_TRY(r1cs_matvec_run<F>(mb, (const Fe<F>*)z, (Fe<F>*)b, m, st));
+        ZK_TRY(r1cs_matvec_run<F>(mc, (const Fe<F>*)z, (Fe<F>*)c, m, st));
+        // the input-consistency rows: a[num_constraints + j] = z[j]
+        if (num_inputs) HIP_TRY(hipMemcpyAsync((Fe<F>*)a + nc, z, num_inputs * sizeof(Fe<F>), hipMemcpyDeviceToDevice, st));
+        return witness_map_run<F>(dc, (int)f, (Fe<F>*)a, (Fe<F>*)b, (Fe<F>*)c, log_m, st);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+
+// ---- halo2 prover steps beyond commit / FFT (include/zkcp_amd_prover.h)
+API int zk_batch_invert_device(zk_field_t f, void* a, uint64_t n, void* stream) {
+    if (n && (!a || !aligned16(a))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(a);
+    FIELD_SWITCH(f, return batch_invert_run<F>((Fe<F>*)a, n, (hipStream_t)stream));
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_prefix_product_device(zk_field_t f, const void* in, void* out, uint64_t n, const void* first, void* total_host, void* stream) {
+    if (n && (!in || !out || !aligned16(in) || !aligned16(out))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(out);
+    FIELD_SWITCH(f, {
+        Fe<F> fst;
+        fe_one(fst);
+        if (first) host_load(fst, first);
+        Fe<F>* total = nullptr;
+        ZK_TRY(prefix_product_run<F>(dc, (const Fe<F>*)in, (Fe<F>*)out, n, fst, &total, (hipStream_t)stream));
+        if (total_host) {
+            HIP_TRY(hipMemcpyAsync(total_host, total, sizeof(Fe<F>), hipMemcpyDeviceToHost, (hipStream_t)stream));
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        }
+        return ZK_OK;
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_halo2_permutation_product_device(zk_field_t f, uint32_t ncols, const void* const* cols, const void* const* sigmas, uint32_t first_col,
+                                            const void* beta, const void* gamma, const void* delta, uint32_t k, const void* z_first, void* z_out,
+                                            void* z_last_host, void* stream) {
+    if (!cols || !sigmas || !beta || !gamma || !delta || !z_out || !aligned16(z_out) || ncols == 0 || ncols > 8) return ZK_ERR_INVALID_ARG;
+    for (uint32_t c = 0; c < ncols; c++)
+        if (!cols[c] || !sigmas[c] || !aligned16(cols[c]) || !aligned16(sigmas[c])) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(z_out);
+    FIELD_SWITCH(f, {
+        if (k > (uint32_t)F::TWO_ADICITY || k > 30) return ZK_ERR_INVALID_ARG;
+        Fe<F> b, g_, d, fst, w;
+        host_load(b, beta);
+        host_load(g_, gamma);
+        host_load(d, delta);
+        fe_one(fst);
+        if (z_first) host_load(fst, z_first);
+        for (int i = 0; i < F::N; i++) w.v[i] = F::ROOT[i];
+        for (uint32_t i = k; i < (uint32_t)F::TWO_ADICITY; i++) fe_sqr(w, w);
+        return perm_product_run<F>(dc, (int)f, ncols, cols, sigmas, first_col, b, g_, d, k, w, fst, (Fe<F>*)z_out, z_last_host, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_halo2_lookup_product_device(zk_field_t f, const void* a, const void* s, const void* ap, const void* sp, const void* beta,
+                                       const void* gamma, uint64_t n, void* z_out, void* z_last_host, void* stream) {
+    if (!beta || !gamma || (n && (!a || !s || !ap || !sp || !z_out || !aligned16(a) || !aligned16(s) || !aligned16(ap) || !aligned16(sp) || !aligned16(z_out))))
+        return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(z_out);
+    FIELD_SWITCH(f, {
+        Fe<F> b, g_, one;
+        host_load(b, beta);
+        host_load(g_, gamma);
+        fe_one(one);
+        return lookup_product_run<F>(dc, (const Fe<F>*)a, (const Fe<F>*)s, (const Fe<F>*)ap, (const Fe<F>*)sp, b, g_, n, one, (Fe<F>*)z_out,
+                                     z_last_host, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_inner_product_device(zk_field_t f, const void* a, const void* b, uint64_t n, void* out_host, void* stream) {
+    if (!out_host || (n && (!a || !b || !aligned16(a) || !aligned16(b)))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(a);
+    FIELD_SWITCH(f, return inner_product_run<F>(dc, (const Fe<F>*)a, (const Fe<F>*)b, n, out_host, (hipStream_t)stream));
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_vec_fold_device(zk_field_t f, void* a, uint64_t half, const void* c, void* stream) {
+    if (!c || (half && (!a || !aligned16(a)))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(a);
+    FIELD_SWITCH(f, {
+        Fe<F> cc;
+        host_load(cc, c);
+        return vec_fold_run<F>((Fe<F>*)a, half, cc, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_ipa_fold_bases_device(zk_curve_t c, void* g_aff, uint64_t half, const void* u_mont, void* stream) {
+    if (!u_mont || (half && (!g_aff || !aligned16(g_aff)))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(g_aff);
+    CURVE_SWITCH(c, {
+        Fe<typename C::Fr> u;
+        host_load(u, u_mont);
+        fe_from_mont(u, u);
+        return ipa_fold_bases_run<C>(dc, (Affine<C>*)g_aff, half, u, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_expr_eval_device(zk_field_t f, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const void* consts,
+                            uint32_t n_consts, uint32_t log_n, uint32_t rot_scale, void* out, void* stream) {
+    if (!prog || !out || !aligned16(out) || (n_cols && !cols) || (n_consts && !consts)) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(out);
+    FIELD_SWITCH(f, return expr_eval_run<F>(dc, prog, n_ops, cols, n_cols, (const Fe<F>*)consts, n_consts, log_n, rot_scale, (Fe<F>*)out,
+                                            (hipStream_t)stream));
     return ZK_ERR_INVALID_ARG;
 }
 

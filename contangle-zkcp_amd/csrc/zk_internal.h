@@ -106,6 +106,7 @@ struct StreamScratch {
     hipStream_t stream = nullptr;
     uint64_t stamp = 0;
     DevBuf ntt_tmp, fb_table, fb_tmp;
+    DevBuf poly_a, poly_b, poly_tot;   // numerators / denominators / block totals of the grand-product and IPA helpers
 };
 
 constexpr int ZK_MAX_JOBS = 4;

@@ -342,4 +342,25 @@ int fixed_base_msm_run(DeviceCtx& dc, const Affine<C>& base, const Fe<typename C
     HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
+// g[i] <- affine(g[i] + [u] g[i + half]) for i < half (u canonical)
+template <class C>
+int ipa_fold_bases_run(DeviceCtx& dc, Affine<C>* gens, uint64_t half, const Fe<typename C::Fr>& u_canonical, hipStream_t st) {
+    if (half == 0) return ZK_OK;
+    if (half >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    ZK_TRY(ws_get(ss->fb_tmp, (size_t)half * sizeof(XYZZ<C>)));
+    XYZZ<C>* tmp = (XYZZ<C>*)ss->fb_tmp.p;
+    int top = -1;
+    for (int b = 32 * C::Fr::N - 1; b >= 0; b--)
+        if ((u_canonical.v[b >> 5] >> (b & 31)) & 1) {
+            top = b;
+            break;
+        }
+    ZK_LAUNCH((ipa_fold_bases_kernel<C>), (unsigned)((half + 63) / 64), 64, 0, st, (const Affine<C>*)gens, tmp, (uint32_t)half, u_canonical, top);
+    const uint64_t lanes = (half + FB_K - 1) / FB_K;
+    ZK_LAUNCH((xyzz_batch_to_affine_kernel<C>), (unsigned)((lanes + 63) / 64), 64, 0, st, (const XYZZ<C>*)tmp, gens, (uint32_t)half);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
 }  // namespace zk

@@ -12,4 +12,6 @@ int fixed_base_run(const Fe<typename C::Fr>* d_scalars, uint64_t n, Affine<C>* d
 template <class C>
 int fixed_base_msm_run(DeviceCtx& dc, const Affine<C>& base, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, Affine<C>* d_out,
                        hipStream_t st);
+template <class C>
+int ipa_fold_bases_run(DeviceCtx& dc, Affine<C>* g, uint64_t half, const Fe<typename C::Fr>& u_canonical, hipStream_t st);
 }  // namespace zk

@@ -923,6 +923,26 @@ __global__ void __launch_bounds__(64) fixed_base_mul_kernel(const Fe<typename C:
     out[i] = r;
 }
 
+// halo2_proofs 0.2 poly/commitment/prover.rs parallel_generator_collapse (one IPA round): tmp[i] = g[i] + [u] g[i + half].
+// The challenge u is the same for every lane (canonical words in SGPRs), so the double-and-add has wave-uniform control
+// flow; xyzz_batch_to_affine_kernel then writes the folded generators back as affine points (batch_normalize upstream).
+template <class C>
+__global__ void __launch_bounds__(64) ipa_fold_bases_kernel(const Affine<C>* __restrict__ g, XYZZ<C>* __restrict__ tmp, uint32_t half,
+                                                            Fe<typename C::Fr> u, int top_bit) {
+    using Fr = typename C::Fr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const Affine<C> hi = g[i + half], lo = g[i];
+    XYZZ<C> acc;
+    xyzz_set_inf(acc);
+    for (int bit = top_bit; bit >= 0; bit--) {
+        xyzz_dbl(acc);
+        if ((word_at<Fr::N>(u.v, bit >> 5) >> (bit & 31)) & 1) xyzz_add_mixed(acc, hi);
+    }
+    xyzz_add_mixed(acc, lo);
+    tmp[i] = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // Fixed-base windowed scalar multiplication: out[i] = [k_i] B for ONE base B -- ark-ec 0.3 `FixedBaseMSM::get_window_table`
 // + `FixedBaseMSM::multi_scalar_mul` + `ProjectiveCurve::batch_normalization_into_affine`, the shape of Groth16 key

@@ -3,6 +3,7 @@
 #include "zk_internal.h"
 #include "zk_ntt_decl.h"
 #include "zk_ntt_kernels.h"
+#include "zk_r1cs_kernels.h"
 namespace zk {
 // ------------------------------------------------------------------ NTT
 struct NttPlan {
@@ -276,6 +277,22 @@ int scale_periodic_run(Fe<F>* a, uint64_t n, const Fe<F>* table_host, uint32_t m
     return ZK_OK;
 }
 
+// out[0 .. n_rows) = M z, out[n_rows .. out_len) = 0   (CSR matrix resident on the device, see zk_r1cs_kernels.h)
+template <class F>
+int r1cs_matvec_run(const R1csMatrix& m, const Fe<F>* z, Fe<F>* out, uint64_t out_len, hipStream_t st) {
+    if (out_len < m.n_rows) return ZK_ERR_INVALID_ARG;
+    if (out_len == 0) return ZK_OK;
+    uint64_t blocks = (out_len + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    ZK_LAUNCH((r1cs_matvec_kernel<F>), (unsigned)blocks, 256, 0, st, (const uint64_t*)m.row_ptr, (const uint32_t*)m.col, (const Fe<F>*)m.val, z,
+              out, m.n_rows, out_len);
+    if (m.n_long)
+        ZK_LAUNCH((r1cs_matvec_long_kernel<F>), (unsigned)m.n_long, 256, 0, st, (const uint64_t*)m.row_ptr, (const uint32_t*)m.col,
+                  (const Fe<F>*)m.val, z, out, (const uint64_t*)m.long_rows);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
 // ark-groth16 0.3 r1cs_to_qap.rs  R1CStoQAP::witness_map, from the point where a, b, c hold the evaluations
 // <A_i,z>, <B_i,z>, <C_i,z> on the size-m domain: seven NTTs and the pointwise glue, all in HBM.
 //   ifft(a); ifft(b); coset_fft(a); coset_fft(b); ifft(c); coset_fft(c);
@@ -308,3 +325,4 @@ int witness_map_run(DeviceCtx& dc, int field, Fe<F>* a, Fe<F>* b, Fe<F>* c, uint
     return ZK_OK;
 }
 }  // namespace zk
+#include "zk_poly.inl"

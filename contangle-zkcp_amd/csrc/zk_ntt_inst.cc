@@ -5,5 +5,16 @@ template int ntt_run<ZK_FIELD>(DeviceCtx&, int, Fe<ZK_FIELD>*, uint32_t, const F
 template int coset_run<ZK_FIELD>(DeviceCtx&, int, Fe<ZK_FIELD>*, uint32_t, const Fe<ZK_FIELD>&, hipStream_t);
 template int vec_op_run<ZK_FIELD>(Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, uint64_t, int, const Fe<ZK_FIELD>&, hipStream_t);
 template int scale_periodic_run<ZK_FIELD>(Fe<ZK_FIELD>*, uint64_t, const Fe<ZK_FIELD>*, uint32_t, hipStream_t);
+template int batch_invert_run<ZK_FIELD>(Fe<ZK_FIELD>*, uint64_t, hipStream_t);
+template int prefix_product_run<ZK_FIELD>(DeviceCtx&, const Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, uint64_t, const Fe<ZK_FIELD>&, Fe<ZK_FIELD>**, hipStream_t);
+template int perm_product_run<ZK_FIELD>(DeviceCtx&, int, uint32_t, const void* const*, const void* const*, uint32_t, const Fe<ZK_FIELD>&, const Fe<ZK_FIELD>&,
+                                        const Fe<ZK_FIELD>&, uint32_t, const Fe<ZK_FIELD>&, const Fe<ZK_FIELD>&, Fe<ZK_FIELD>*, void*, hipStream_t);
+template int lookup_product_run<ZK_FIELD>(DeviceCtx&, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>&,
+                                          const Fe<ZK_FIELD>&, uint64_t, const Fe<ZK_FIELD>&, Fe<ZK_FIELD>*, void*, hipStream_t);
+template int inner_product_run<ZK_FIELD>(DeviceCtx&, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, uint64_t, void*, hipStream_t);
+template int vec_fold_run<ZK_FIELD>(Fe<ZK_FIELD>*, uint64_t, const Fe<ZK_FIELD>&, hipStream_t);
+template int expr_eval_run<ZK_FIELD>(DeviceCtx&, const zk_expr_op*, uint32_t, const void* const*, uint32_t, const Fe<ZK_FIELD>*, uint32_t, uint32_t, uint32_t,
+                                     Fe<ZK_FIELD>*, hipStream_t);
+template int r1cs_matvec_run<ZK_FIELD>(const R1csMatrix&, const Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, uint64_t, hipStream_t);
 template int witness_map_run<ZK_FIELD>(DeviceCtx&, int, Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, uint32_t, hipStream_t);
 }  // namespace zk

@@ -1,0 +1,168 @@
+// Launch sequences of the halo2 prover steps beyond commit / FFT (zk_poly_kernels.h).  Included by zk_ntt.inl, once per
+// scalar field.  Scratch (numerators / denominators, block totals, partial sums) belongs to the caller's stream.
+#pragma once
+#include "zk_poly_kernels.h"
+namespace zk {
+
+template <class F>
+int batch_invert_run(Fe<F>* a, uint64_t n, hipStream_t st) {
+    if (n == 0) return ZK_OK;
+    const uint64_t lanes = (n + INV_K - 1) / INV_K;
+    ZK_LAUNCH((batch_invert_kernel<F>), (unsigned)((lanes + 63) / 64), 64, 0, st, a, n);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+// out[i] = first * prod_{j < i} in[j]  (in == out allowed); *total_dev (one element of scratch) = first * prod of all
+template <class F>
+int prefix_product_run(DeviceCtx& dc, const Fe<F>* in, Fe<F>* out, uint64_t n, const Fe<F>& first, Fe<F>** total_dev, hipStream_t st) {
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    const uint64_t per_wg = (uint64_t)SCAN_WG * SCAN_K;
+    const uint64_t nblocks = n ? (n + per_wg - 1) / per_wg : 1;
+    if (nblocks > (1u << 24)) return ZK_ERR_UNSUPPORTED;
+    ZK_TRY(ws_get(ss->poly_tot, (nblocks + 1) * sizeof(Fe<F>)));
+    Fe<F>* tot = (Fe<F>*)ss->poly_tot.p;
+    if (n) ZK_LAUNCH((scan_block_kernel<F>), (unsigned)nblocks, SCAN_WG, 0, st, in, out, tot, n);
+    else HIP_TRY(hipMemcpyAsync(tot, F::R, sizeof(Fe<F>), hipMemcpyHostToDevice, st));
+    ZK_LAUNCH((scan_totals_kernel<F>), 1, SCAN_WG, 0, st, tot, (uint32_t)nblocks, first, tot + nblocks);
+    if (n) ZK_LAUNCH((scan_apply_kernel<F>), (unsigned)nblocks, SCAN_WG, 0, st, out, (const Fe<F>*)tot, n);
+    HIP_TRY(hipGetLastError());
+    if (total_dev) *total_dev = tot + nblocks;
+    return ZK_OK;
+}
+
+// f = num / den elementwise (den is inverted in place), then z = exclusive product scan of f
+template <class F>
+int ratio_scan_run(DeviceCtx& dc, Fe<F>* num, Fe<F>* den, uint64_t n, const Fe<F>& first, Fe<F>* z_out, void* total_host, hipStream_t st) {
+    ZK_TRY(batch_invert_run<F>(den, n, st));
+    Fe<F> one;
+    fe_one(one);
+    ZK_TRY(vec_op_run<F>(num, den, nullptr, n, VEC_MUL, one, st));
+    Fe<F>* total = nullptr;
+    ZK_TRY(prefix_product_run<F>(dc, num, z_out, n, first, &total, st));
+    if (total_host) {
+        HIP_TRY(hipMemcpyAsync(total_host, total, sizeof(Fe<F>), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return ZK_OK;
+}
+
+template <class F>
+int perm_product_run(DeviceCtx& dc, int field, uint32_t ncols, const void* const* cols, const void* const* sigmas, uint32_t first_col,
+                     const Fe<F>& beta, const Fe<F>& gamma, const Fe<F>& delta, uint32_t k, const Fe<F>& omega, const Fe<F>& first, Fe<F>* z_out,
+                     void* total_host, hipStream_t st) {
+    if (ncols == 0 || ncols > 8 || k > 30) return ZK_ERR_INVALID_ARG;
+    const uint64_t n = 1ull << k;
+    PermChunk<F> ch;
+    memset(&ch, 0, sizeof ch);
+    ch.ncols = ncols;
+    ch.beta = beta;
+    ch.gamma = gamma;
+    Fe<F> dp;
+    fe_one(dp);
+    for (uint32_t c = 0; c < first_col; c++) fe_mul(dp, dp, delta);
+    for (uint32_t c = 0; c < ncols; c++) {
+        if (!cols[c] || !sigmas[c]) return ZK_ERR_INVALID_ARG;
+        ch.col[c] = (const Fe<F>*)cols[c];
+        ch.sigma[c] = (const Fe<F>*)sigmas[c];
+        fe_mul(ch.dcoef[c], dp, beta);
+        fe_mul(dp, dp, delta);
+    }
+    PowTables<F> wpow;
+    ZK_TRY(pow_tables<F>(dc, omega, k, field, st, &wpow));
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    ZK_TRY(ws_get(ss->poly_a, n * sizeof(Fe<F>)));
+    ZK_TRY(ws_get(ss->poly_b, n * sizeof(Fe<F>)));
+    Fe<F>*num = (Fe<F>*)ss->poly_a.p, *den = (Fe<F>*)ss->poly_b.p;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ZK_LAUNCH((perm_factors_kernel<F>), (unsigned)blocks, 256, 0, st, ch, wpow, num, den, n);
+    return ratio_scan_run<F>(dc, num, den, n, first, z_out, total_host, st);
+}
+
+template <class F>
+int lookup_product_run(DeviceCtx& dc, const Fe<F>* A, const Fe<F>* S, const Fe<F>* Ap, const Fe<F>* Sp, const Fe<F>& beta, const Fe<F>& gamma,
+                       uint64_t n, const Fe<F>& first, Fe<F>* z_out, void* total_host, hipStream_t st) {
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    ZK_TRY(ws_get(ss->poly_a, (n ? n : 1) * sizeof(Fe<F>)));
+    ZK_TRY(ws_get(ss->poly_b, (n ? n : 1) * sizeof(Fe<F>)));
+    Fe<F>*num = (Fe<F>*)ss->poly_a.p, *den = (Fe<F>*)ss->poly_b.p;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (n) ZK_LAUNCH((lookup_factors_kernel<F>), (unsigned)blocks, 256, 0, st, A, S, Ap, Sp, beta, gamma, num, den, n);
+    return ratio_scan_run<F>(dc, num, den, n, first, z_out, total_host, st);
+}
+
+// <a, b>: per-workgroup partial sums, added on the host (synchronises the stream)
+template <class F>
+int inner_product_run(DeviceCtx& dc, const Fe<F>* a, const Fe<F>* b, uint64_t n, void* out_host, hipStream_t st) {
+    Fe<F> acc;
+    fe_zero(acc);
+    if (n) {
+        StreamScratch* ss = nullptr;
+        ZK_TRY(stream_scratch(dc, st, &ss));
+        uint64_t blocks = (n + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        ZK_TRY(ws_get(ss->poly_tot, blocks * sizeof(Fe<F>)));
+        ZK_LAUNCH((inner_product_kernel<F>), (unsigned)blocks, 256, 0, st, a, b, n, (Fe<F>*)ss->poly_tot.p);
+        HIP_TRY(hipGetLastError());
+        std::vector<Fe<F>> part(blocks);
+        HIP_TRY(hipMemcpyAsync(part.data(), ss->poly_tot.p, blocks * sizeof(Fe<F>), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (auto& p : part) fe_add(acc, acc, p);
+    }
+    host_store(out_host, acc);
+    return ZK_OK;
+}
+
+template <class F>
+int vec_fold_run(Fe<F>* a, uint64_t half, const Fe<F>& c, hipStream_t st) {
+    if (half == 0) return ZK_OK;
+    uint64_t blocks = (half + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ZK_LAUNCH((vec_fold_kernel<F>), (unsigned)blocks, 256, 0, st, a, half, c);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+// program / column table / constants are copied to the stream's scratch, then one grid-stride launch
+template <class F>
+int expr_eval_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const Fe<F>* consts,
+                  uint32_t n_consts, uint32_t log_n, uint32_t rot_scale, Fe<F>* out, hipStream_t st) {
+    if (n_ops == 0 || n_ops > EXPR_MAX_OPS || n_cols > EXPR_MAX_COLS || n_consts > EXPR_MAX_CONSTS || log_n > 30) return ZK_ERR_INVALID_ARG;
+    static_assert(sizeof(zk_expr_op) == sizeof(ExprOp), "ABI struct = kernel struct");
+    // validate the program on the host: stack depth, operand indices -- a kernel must never index past its tables
+    int depth = 0;
+    for (uint32_t k = 0; k < n_ops; k++) {
+        const zk_expr_op& o = prog[k];
+        if (o.op > 6) return ZK_ERR_INVALID_ARG;
+        if (o.op == 0 && (o.arg >= n_cols || !cols[o.arg])) return ZK_ERR_INVALID_ARG;
+        if ((o.op == 1 || o.op == 6) && o.arg >= n_consts) return ZK_ERR_INVALID_ARG;
+        if (o.op <= 1) depth++;
+        else if (o.op == 5 || o.op == 6) { if (depth < 1) return ZK_ERR_INVALID_ARG; }
+        else { if (depth < 2) return ZK_ERR_INVALID_ARG; depth--; }
+        if (depth > (int)EXPR_STACK) return ZK_ERR_UNSUPPORTED;
+    }
+    if (depth != 1) return ZK_ERR_INVALID_ARG;
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    const size_t pb = sizeof(ExprOp) * EXPR_MAX_OPS, cb = sizeof(void*) * EXPR_MAX_COLS, kb = sizeof(Fe<F>) * EXPR_MAX_CONSTS;
+    ZK_TRY(ws_get(ss->poly_tot, pb + cb + kb + 64));
+    unsigned char* base = (unsigned char*)ss->poly_tot.p;
+    HIP_TRY(hipMemcpyAsync(base, prog, sizeof(ExprOp) * n_ops, hipMemcpyHostToDevice, st));
+    if (n_cols) HIP_TRY(hipMemcpyAsync(base + pb, cols, sizeof(void*) * n_cols, hipMemcpyHostToDevice, st));
+    if (n_consts) HIP_TRY(hipMemcpyAsync(base + pb + cb, consts, sizeof(Fe<F>) * n_consts, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // the sources are the caller's host memory
+    const uint64_t n = 1ull << log_n;
+    uint64_t blocks = (n + EXPR_WG - 1) / EXPR_WG;
+    if (blocks > 8192) blocks = 8192;
+    ZK_LAUNCH((expr_eval_kernel<F>), (unsigned)blocks, EXPR_WG, 0, st, (const ExprOp*)base, n_ops, (const Fe<F>* const*)(base + pb),
+              (const Fe<F>*)(base + pb + cb), log_n, rot_scale, out);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+}  // namespace zk

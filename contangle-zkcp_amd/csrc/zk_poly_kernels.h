@@ -1,0 +1,301 @@
+// Field-side kernels of the halo2 prover steps beyond commit / FFT (halo2_proofs 0.2):
+//   batch_invert_kernel            arithmetic.rs BatchInvert (Montgomery's trick, K elements per lane share one inversion; 0 stays 0)
+//   scan_block / scan_totals / scan_apply   the grand products Z of the permutation and lookup arguments
+//                                  (plonk/permutation/prover.rs, plonk/lookup/prover.rs): z[i] = first * prod_{j<i} f[j]
+//   perm_factors_kernel            numerator and denominator of one chunk of permutation columns, row by row
+//   lookup_factors_kernel          (A + beta)(S + gamma) and (A' + beta)(S' + gamma)
+//   inner_product_kernel           compute_inner_product (the value_l / value_r of an IPA round)
+//   vec_fold_kernel                a[i] += c a[i + half]  (the p' and b folds of an IPA round)
+//   expr_eval_kernel               the quotient numerator: a stack program over extended-domain columns with rotations
+// All HBM-streaming with a handful of Montgomery products per element; the scans are three launches (block products,
+// scan of the block totals by one workgroup, apply).
+#pragma once
+#include "zk_rt.h"
+#include "zk_field.h"
+#include "zk_ntt_kernels.h"
+
+namespace zk {
+
+constexpr uint32_t INV_K = 16;     // elements per lane and inversion
+constexpr uint32_t SCAN_K = 16;    // elements per lane of a scan workgroup (256 lanes: 4096 elements per workgroup)
+constexpr uint32_t SCAN_WG = 256;
+
+// a[i] <- 1 / a[i] (0 -> 0).  Lane t owns a[t*K .. (t+1)*K): prefix products, ONE Fermat inversion, back-substitution.
+template <class F>
+__global__ void __launch_bounds__(64) batch_invert_kernel(Fe<F>* __restrict__ a, uint64_t n) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo = t * INV_K;
+    if (lo >= n) return;
+    const uint32_t cnt = n - lo < INV_K ? (uint32_t)(n - lo) : INV_K;
+    Fe<F> pre[INV_K], run;
+    fe_one(run);
+    for (uint32_t k = 0; k < cnt; k++) {
+        pre[k] = run;
+        Fe<F> x = a[lo + k];
+        if (!fe_is_zero(x)) fe_mul(run, run, x);      // a zero contributes a factor 1 and stays zero
+    }
+    Fe<F> inv;
+    fe_inv(inv, run);
+    for (int k = (int)cnt - 1; k >= 0; k--) {
+        Fe<F> x = a[lo + k];
+        if (fe_is_zero(x)) continue;
+        Fe<F> r;
+        fe_mul(r, inv, pre[k]);
+        fe_mul(inv, inv, x);
+        a[lo + k] = r;
+    }
+}
+
+// ---- exclusive multiplicative scan ----
+// phase 1: workgroup b covers elements [b*4096, +4096): out[i] = product of the elements before i INSIDE the workgroup's
+// range; block_tot[b] = product of the whole range
+template <class F>
+__global__ void __launch_bounds__(SCAN_WG) scan_block_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out, Fe<F>* __restrict__ block_tot,
+                                                            uint64_t n) {
+    __shared__ Fe<F> part[SCAN_WG];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t lo = ((uint64_t)blockIdx.x * SCAN_WG + tid) * SCAN_K;
+    Fe<F> v[SCAN_K], run;
+    fe_one(run);
+    for (uint32_t k = 0; k < SCAN_K; k++) {
+        if (lo + k < n) {
+            v[k] = in[lo + k];
+            fe_mul(run, run, v[k]);
+        } else {
+            fe_one(v[k]);
+        }
+    }
+    part[tid] = run;
+    __syncthreads();
+    Fe<F> acc = run;
+    for (uint32_t d = 1; d < SCAN_WG; d <<= 1) {     // inclusive Hillis-Steele over the lane products
+        Fe<F> o;
+        const bool on = tid >= d;
+        if (on) o = part[tid - d];
+        __syncthreads();
+        if (on) {
+            fe_mul(acc, acc, o);
+            part[tid] = acc;
+        }
+        __syncthreads();
+    }
+    Fe<F> pre;   // exclusive prefix of this lane
+    if (tid == 0)
+        fe_one(pre);
+    else
+        pre = part[tid - 1];
+    if (tid == SCAN_WG - 1) block_tot[blockIdx.x] = acc;
+    for (uint32_t k = 0; k < SCAN_K; k++) {
+        if (lo + k < n) out[lo + k] = pre;
+        fe_mul(pre, pre, v[k]);
+    }
+}
+// phase 2 (one workgroup): block_tot[b] <- first * product of block_tot[0 .. b); total_out = first * product of all
+template <class F>
+__global__ void __launch_bounds__(SCAN_WG) scan_totals_kernel(Fe<F>* __restrict__ block_tot, uint32_t nblocks, Fe<F> first, Fe<F>* __restrict__ total_out) {
+    __shared__ Fe<F> part[SCAN_WG];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (nblocks + SCAN_WG - 1) / SCAN_WG;
+    const uint32_t lo = tid * per < nblocks ? tid * per : nblocks, hi = lo + per < nblocks ? lo + per : nblocks;
+    Fe<F> run;
+    fe_one(run);
+    for (uint32_t j = lo; j < hi; j++) {
+        Fe<F> x = block_tot[j];
+        fe_mul(run, run, x);
+    }
+    part[tid] = run;
+    __syncthreads();
+    Fe<F> acc = run;
+    for (uint32_t d = 1; d < SCAN_WG; d <<= 1) {
+        Fe<F> o;
+        const bool on = tid >= d;
+        if (on) o = part[tid - d];
+        __syncthreads();
+        if (on) {
+            fe_mul(acc, acc, o);
+            part[tid] = acc;
+        }
+        __syncthreads();
+    }
+    Fe<F> pre = first;
+    if (tid > 0) {
+        Fe<F> o = part[tid - 1];
+        fe_mul(pre, pre, o);
+    }
+    for (uint32_t j = lo; j < hi; j++) {
+        Fe<F> x = block_tot[j];
+        block_tot[j] = pre;
+        fe_mul(pre, pre, x);
+    }
+    if (tid == SCAN_WG - 1) *total_out = pre;   // (the last lane's range ends at nblocks)
+}
+// phase 3: out[i] *= block_tot[block of i]
+template <class F>
+__global__ void __launch_bounds__(SCAN_WG) scan_apply_kernel(Fe<F>* __restrict__ out, const Fe<F>* __restrict__ block_tot, uint64_t n) {
+    const Fe<F> off = block_tot[blockIdx.x];
+    const uint64_t lo = ((uint64_t)blockIdx.x * SCAN_WG + threadIdx.x) * SCAN_K;
+    for (uint32_t k = 0; k < SCAN_K; k++) {
+        if (lo + k < n) {
+            Fe<F> x = out[lo + k];
+            fe_mul(x, x, off);
+            out[lo + k] = x;
+        }
+    }
+}
+
+// ---- permutation argument, one chunk of <= 8 columns ----
+template <class F>
+struct PermChunk {
+    const Fe<F>* col[8];
+    const Fe<F>* sigma[8];
+    Fe<F> dcoef[8];      // beta * delta^(index of the column in the whole argument)
+    Fe<F> beta, gamma;
+    uint32_t ncols;
+};
+// num[i] = prod_c (v_c[i] + dcoef_c omega^i + gamma) ; den[i] = prod_c (v_c[i] + beta sigma_c[i] + gamma)
+template <class F>
+__global__ void __launch_bounds__(256) perm_factors_kernel(PermChunk<F> ch, PowTables<F> wpow, Fe<F>* __restrict__ num, Fe<F>* __restrict__ den,
+                                                           uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<F> w, a, b;
+        fe_one(w);
+        mul_pow(w, wpow, i);      // omega^i
+        fe_one(a);
+        fe_one(b);
+        for (uint32_t c = 0; c < ch.ncols; c++) {
+            Fe<F> v = ch.col[c][i], s = ch.sigma[c][i], t, u;
+            fe_mul(t, ch.dcoef[c], w);
+            fe_add(t, t, v);
+            fe_add(t, t, ch.gamma);
+            fe_mul(a, a, t);
+            fe_mul(u, ch.beta, s);
+            fe_add(u, u, v);
+            fe_add(u, u, ch.gamma);
+            fe_mul(b, b, u);
+        }
+        num[i] = a;
+        den[i] = b;
+    }
+}
+// num[i] = (A + beta)(S + gamma), den[i] = (A' + beta)(S' + gamma)
+template <class F>
+__global__ void __launch_bounds__(256) lookup_factors_kernel(const Fe<F>* __restrict__ A, const Fe<F>* __restrict__ S, const Fe<F>* __restrict__ Ap,
+                                                             const Fe<F>* __restrict__ Sp, Fe<F> beta, Fe<F> gamma, Fe<F>* __restrict__ num,
+                                                             Fe<F>* __restrict__ den, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<F> a = A[i], s = S[i], ap = Ap[i], sp = Sp[i];
+        fe_add(a, a, beta);
+        fe_add(s, s, gamma);
+        fe_mul(a, a, s);
+        fe_add(ap, ap, beta);
+        fe_add(sp, sp, gamma);
+        fe_mul(ap, ap, sp);
+        num[i] = a;
+        den[i] = ap;
+    }
+}
+
+// ---- IPA scalar side ----
+// partial[b] = sum over the workgroup's grid-stride share of a[i] b[i]
+template <class F>
+__global__ void __launch_bounds__(256) inner_product_kernel(const Fe<F>* __restrict__ a, const Fe<F>* __restrict__ b, uint64_t n, Fe<F>* __restrict__ partial) {
+    __shared__ Fe<F> part[256];
+    Fe<F> acc;
+    fe_zero(acc);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<F> x = a[i], y = b[i];
+        fe_mul(x, x, y);
+        fe_add(acc, acc, x);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+            Fe<F> o = part[threadIdx.x + d];
+            fe_add(acc, acc, o);
+            part[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+// a[i] += c * a[i + half], i < half
+template <class F>
+__global__ void __launch_bounds__(256) vec_fold_kernel(Fe<F>* __restrict__ a, uint64_t half, Fe<F> c) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<F> x = a[i], y = a[i + half];
+        fe_mul(y, y, c);
+        fe_add(x, x, y);
+        a[i] = x;
+    }
+}
+
+// ---- quotient numerator: a stack program evaluated at every row of the extended domain ----
+// (halo2_proofs 0.2 plonk/prover.rs: every gate polynomial, multiplied into the running sum by y, is an Expression over
+// advice / fixed / instance columns with rotations, evaluated on the extended coset; a rotation by r rows is a shift of
+// r * 2^(extended_k - k) positions there)
+struct ExprOp {
+    uint8_t op;      // 0 col(arg = column, rot)  1 const(arg)  2 add  3 sub  4 mul  5 neg  6 scale(arg = constant)
+    uint8_t pad;
+    int16_t rot;
+    uint32_t arg;
+};
+constexpr uint32_t EXPR_MAX_OPS = 512, EXPR_MAX_COLS = 64, EXPR_MAX_CONSTS = 32, EXPR_STACK = 8, EXPR_WG = 128;
+
+// LDS: per-lane stack, limb-major (bank-conflict-free): stack[(slot * N + limb) * EXPR_WG + lane]
+template <class F>
+__global__ void __launch_bounds__(EXPR_WG) expr_eval_kernel(const ExprOp* __restrict__ prog, uint32_t n_ops, const Fe<F>* const* __restrict__ cols,
+                                                            const Fe<F>* __restrict__ consts, uint32_t log_n, uint32_t rot_scale,
+                                                            Fe<F>* __restrict__ out) {
+    __shared__ uint32_t stack[EXPR_STACK * F::N * EXPR_WG];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t n = 1ull << log_n, mask = n - 1;
+    auto push = [&](uint32_t sp, const Fe<F>& x) {
+        ZK_UNROLL
+        for (int l = 0; l < F::N; l++) stack[(sp * F::N + l) * EXPR_WG + lane] = x.v[l];
+    };
+    auto peek = [&](uint32_t sp, Fe<F>& x) {
+        ZK_UNROLL
+        for (int l = 0; l < F::N; l++) x.v[l] = stack[(sp * F::N + l) * EXPR_WG + lane];
+    };
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + lane; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t sp = 0;
+        for (uint32_t k = 0; k < n_ops; k++) {
+            const ExprOp o = prog[k];
+            Fe<F> x, y;
+            if (o.op == 0) {
+                const uint64_t j = (i + (uint64_t)((int64_t)o.rot * (int64_t)rot_scale)) & mask;
+                x = cols[o.arg][j];
+                push(sp++, x);
+            } else if (o.op == 1) {
+                x = consts[o.arg];
+                push(sp++, x);
+            } else if (o.op == 5) {
+                peek(sp - 1, x);
+                fe_neg(x, x);
+                push(sp - 1, x);
+            } else if (o.op == 6) {
+                peek(sp - 1, x);
+                y = consts[o.arg];
+                fe_mul(x, x, y);
+                push(sp - 1, x);
+            } else {
+                peek(sp - 2, x);
+                peek(sp - 1, y);
+                if (o.op == 2)
+                    fe_add(x, x, y);
+                else if (o.op == 3)
+                    fe_sub(x, x, y);
+                else
+                    fe_mul(x, x, y);
+                sp--;
+                push(sp - 1, x);
+            }
+        }
+        Fe<F> r;
+        peek(0, r);
+        out[i] = r;
+    }
+}
+
+}  // namespace zk

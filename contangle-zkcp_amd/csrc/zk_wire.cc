@@ -2,6 +2,7 @@
 // (lib/src/utils.rs:85-118, circuits-ark/src/utils.rs:12-22) and the library's Montgomery limb layout.  Host arithmetic
 // only (the portable field code of zk_field.h); large vectors are converted on all host threads.
 #include "zk_internal.h"
+#include "zk_host64.h"
 #include "zkcp_amd_prover.h"
 
 #include <thread>
@@ -301,6 +302,110 @@ int decode_points(const uint8_t* in, uint64_t n, int compressed, int check, void
     });
 }
 
+// ---- Groth16 proof assembly on 64-bit host limbs (the same view the MSM tail uses)
+template <class C>
+void load_affine_h(HostXYZZ<C>& r, const void* aff) {
+    Affine<C> a;
+    memcpy(&a, aff, 2 * 4 * coord_words<C>());
+    XYZZ<C> x;
+    xyzz_from_affine(x, a);
+    to_host<C>(r, x);
+}
+template <class C>
+void load_jacobian_h(HostXYZZ<C>& r, const void* jac) {
+    Jacobian<C> j;
+    memcpy(&j, jac, 3 * 4 * coord_words<C>());
+    XYZZ<C> x;
+    if (fe_is_zero(j.z)) {
+        xyzz_set_inf(x);
+    } else {
+        x.x = j.x;
+        x.y = j.y;
+        fe_sqr(x.zz, j.z);
+        fe_mul(x.zzz, x.zz, j.z);
+    }
+    to_host<C>(r, x);
+}
+// [k] P for a canonical scalar k (little-endian words), double-and-add, MSB first
+template <class C>
+void scalar_mul_h(HostXYZZ<C>& r, const HostXYZZ<C>& p, const uint32_t* k, int nwords) {
+    HostXYZZ<C> acc;
+    xyzz_set_inf(acc);
+    for (int i = 32 * nwords - 1; i >= 0; i--) {
+        xyzz_dbl(acc);
+        if ((k[i / 32] >> (i % 32)) & 1) xyzz_add(acc, p);
+    }
+    r = acc;
+}
+template <class C>
+void store_affine_h(void* out, const HostXYZZ<C>& p) {
+    XYZZ<C> x;
+    from_host<C>(x, p);
+    Affine<C> a;
+    xyzz_to_affine(a, x);
+    memcpy(out, &a, 2 * 4 * coord_words<C>());
+}
+template <class G1, class G2>
+int assemble(const zk_groth16_assembly* in, void* oa, void* ob, void* oc) {
+    using Fr = typename G1::Fr;
+    Fe<Fr> r, s, rs;
+    memcpy(&r, in->r, sizeof r);
+    memcpy(&s, in->s, sizeof s);
+    fe_mul(rs, r, s);
+    uint32_t rw[Fr::N], sw[Fr::N], rsw[Fr::N];
+    fe_canon<Fr>(rw, r);
+    fe_canon<Fr>(sw, s);
+    fe_canon<Fr>(rsw, rs);
+    HostXYZZ<G1> alpha, beta1, delta1, a0, b10, a_acc, b1_acc, l_acc, h_acc, t, ga, gb1, gc;
+    load_affine_h<G1>(alpha, in->alpha_g1);
+    load_affine_h<G1>(beta1, in->beta_g1);
+    load_affine_h<G1>(delta1, in->delta_g1);
+    load_affine_h<G1>(a0, in->a_query0);
+    load_affine_h<G1>(b10, in->b_g1_query0);
+    load_jacobian_h<G1>(a_acc, in->a_acc);
+    load_jacobian_h<G1>(b1_acc, in->b_g1_acc);
+    load_jacobian_h<G1>(l_acc, in->l_acc);
+    load_jacobian_h<G1>(h_acc, in->h_acc);
+    // A = r delta + a_query[0] + a_acc + alpha          (calculate_coeff(r delta_g1, a_query, alpha_g1, assignment))
+    scalar_mul_h<G1>(ga, delta1, rw, Fr::N);
+    xyzz_add(ga, a0);
+    xyzz_add(ga, a_acc);
+    xyzz_add(ga, alpha);
+    // B1 = s delta + b_g1_query[0] + b_g1_acc + beta_g1
+    scalar_mul_h<G1>(gb1, delta1, sw, Fr::N);
+    xyzz_add(gb1, b10);
+    xyzz_add(gb1, b1_acc);
+    xyzz_add(gb1, beta1);
+    // C = s A + r B1 - r s delta + l_acc + h_acc
+    scalar_mul_h<G1>(gc, ga, sw, Fr::N);
+    scalar_mul_h<G1>(t, gb1, rw, Fr::N);
+    xyzz_add(gc, t);
+    scalar_mul_h<G1>(t, delta1, rsw, Fr::N);
+    {   // subtract: negate y
+        XYZZ<G1> tt;
+        from_host<G1>(tt, t);
+        if (!xyzz_is_inf(tt)) fe_neg(tt.y, tt.y);
+        to_host<G1>(t, tt);
+    }
+    xyzz_add(gc, t);
+    xyzz_add(gc, l_acc);
+    xyzz_add(gc, h_acc);
+    // B = s delta_g2 + b_g2_query[0] + b_g2_acc + beta_g2
+    HostXYZZ<G2> beta2, delta2, b20, b2_acc, gb2;
+    load_affine_h<G2>(beta2, in->beta_g2);
+    load_affine_h<G2>(delta2, in->delta_g2);
+    load_affine_h<G2>(b20, in->b_g2_query0);
+    load_jacobian_h<G2>(b2_acc, in->b_g2_acc);
+    scalar_mul_h<G2>(gb2, delta2, sw, Fr::N);
+    xyzz_add(gb2, b20);
+    xyzz_add(gb2, b2_acc);
+    xyzz_add(gb2, beta2);
+    store_affine_h<G1>(oa, ga);
+    store_affine_h<G2>(ob, gb2);
+    store_affine_h<G1>(oc, gc);
+    return ZK_OK;
+}
+
 bool pairing_curves(zk_pairing_t p, zk_curve_t* g1, zk_curve_t* g2) {
     if (p == ZK_PAIRING_BN254) {
         *g1 = ZK_BN254_G1;
@@ -457,6 +562,16 @@ API int zk_ark_proof_decode(zk_pairing_t p, const uint8_t* in, void* a, void* b,
     ZK_TRY(zk_ark_points_decode(g1, in, 1, 1, 0, a));
     ZK_TRY(zk_ark_points_decode(g2, in + s1, 1, 1, 0, b));
     return zk_ark_points_decode(g1, in + s1 + s2, 1, 1, 0, c);
+}
+
+API int zk_groth16_assemble_proof(zk_pairing_t p, const zk_groth16_assembly* in, void* a, void* b, void* c) {
+    if (!in || !a || !b || !c) return ZK_ERR_INVALID_ARG;
+    const void* const* fields = (const void* const*)in;
+    for (size_t i = 0; i < sizeof(zk_groth16_assembly) / sizeof(void*); i++)
+        if (!fields[i]) return ZK_ERR_INVALID_ARG;
+    if (p == ZK_PAIRING_BN254) return assemble<Bn254G1, Bn254G2>(in, a, b, c);
+    if (p == ZK_PAIRING_BLS12_381) return assemble<Bls381G1, Bls381G2>(in, a, b, c);
+    return ZK_ERR_INVALID_ARG;
 }
 
 }  // extern "C"

@@ -10,9 +10,16 @@ The reference's halo2 crate (circuits-halo2/src/encryption.rs:254-296) never rea
 MockProver -- so they are exercised here as the shape donor for the 2^20-row synthetic workload.
 Same names, argument meaning and assertion behaviour as upstream; the arithmetic runs in the HIP library.
 """
+import ctypes
+
 import numpy as np
 
-from . import (field_id, field_inverse, field_modulus, msm, msm_batch, multiplicative_generator, ntt, root_of_unity, vec_op)
+from . import (Bases, _check, _np64, _ptr, base_limbs, curve_id, field_id, field_inverse, field_modulus, load, msm, msm_batch, msm_submit,
+               multiplicative_generator, ntt, root_of_unity, scalar_field, vec_op)
+
+PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo2_permutation_product_device",
+                  "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
+                  "zk_expr_eval_device"]
 
 
 def best_multiexp(coeffs, bases):
@@ -122,3 +129,134 @@ class EvaluationDomain:
         if int(a_ext.shape[0]) != self.extended_len():
             raise AssertionError("assertion failed: a.values.len() == extended_len")
         return vec_op(self.field, "scale_periodic", a_ext, b=self.t_evaluations, stream=stream)
+
+
+# ------------------------------------------------------------------ prover steps beyond commit / FFT
+class ExprOp(ctypes.Structure):
+    _fields_ = [("op", ctypes.c_uint8), ("pad", ctypes.c_uint8), ("rot", ctypes.c_int16), ("arg", ctypes.c_uint32)]
+
+
+EXPR_CODES = {"col": 0, "const": 1, "add": 2, "sub": 3, "mul": 4, "neg": 5, "scale": 6}
+
+
+def _plib():
+    lib = load()
+    u64, vp, i32, u32 = ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32
+    pp = ctypes.POINTER(ctypes.c_void_p)
+    lib.zk_batch_invert_device.argtypes = [i32, vp, u64, vp]
+    lib.zk_prefix_product_device.argtypes = [i32, vp, vp, u64, vp, vp, vp]
+    lib.zk_halo2_permutation_product_device.argtypes = [i32, u32, pp, pp, u32, vp, vp, vp, u32, vp, vp, vp, vp]
+    lib.zk_halo2_lookup_product_device.argtypes = [i32, vp, vp, vp, vp, vp, vp, u64, vp, vp, vp]
+    lib.zk_inner_product_device.argtypes = [i32, vp, vp, u64, vp, vp]
+    lib.zk_vec_fold_device.argtypes = [i32, vp, u64, vp, vp]
+    lib.zk_ipa_fold_bases_device.argtypes = [i32, vp, u64, vp, vp]
+    lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
+    return lib
+
+
+def _ptr_array(bufs):
+    return (ctypes.c_void_p * len(bufs))(*[ctypes.cast(_ptr(b), ctypes.c_void_p).value for b in bufs])
+
+
+def batch_invert(field, a, stream=0):
+    """arithmetic.rs BatchInvert on a device buffer, in place; zeros stay zero"""
+    _check(_plib().zk_batch_invert_device(field_id(field), _ptr(a), int(a.shape[0]), ctypes.c_void_p(stream)), "zk_batch_invert_device")
+    return a
+
+
+def prefix_product(field, a, out=None, first=None, want_total=False, stream=0):
+    """out[i] = first * prod_{j<i} a[j] (in place when out is None) -> out, or (out, total)"""
+    out = a if out is None else out
+    tot = np.zeros(4, dtype=np.uint64)
+    _check(_plib().zk_prefix_product_device(field_id(field), _ptr(a), _ptr(out), int(a.shape[0]), _ptr(_np64(first)) if first is not None else None,
+                                            _ptr(tot) if want_total else None, ctypes.c_void_p(stream)), "zk_prefix_product_device")
+    return (out, tot) if want_total else out
+
+
+def permutation_product(field, columns, sigmas, beta, gamma, delta, k, z_out, first_column_index=0, z_first=None, stream=0):
+    """plonk/permutation/prover.rs Argument::commit, one chunk (<= 8 columns): fills z_out with Z and returns the value
+    after the last row (the next chunk's z_first)"""
+    last = np.zeros(4, dtype=np.uint64)
+    keep = [_np64(x) for x in (beta, gamma, delta)]
+    zf = _np64(z_first) if z_first is not None else None
+    _check(_plib().zk_halo2_permutation_product_device(field_id(field), len(columns), _ptr_array(columns), _ptr_array(sigmas),
+                                                       first_column_index, _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), k,
+                                                       _ptr(zf) if zf is not None else None, _ptr(z_out), _ptr(last), ctypes.c_void_p(stream)),
+           "zk_halo2_permutation_product_device")
+    return last
+
+
+def lookup_product(field, a, s, a_perm, s_perm, beta, gamma, z_out, stream=0):
+    """plonk/lookup/prover.rs commit_product; returns Z after the last row (must be 1 for a valid lookup)"""
+    last = np.zeros(4, dtype=np.uint64)
+    keep = [_np64(beta), _np64(gamma)]
+    _check(_plib().zk_halo2_lookup_product_device(field_id(field), _ptr(a), _ptr(s), _ptr(a_perm), _ptr(s_perm), _ptr(keep[0]), _ptr(keep[1]),
+                                                  int(a.shape[0]), _ptr(z_out), _ptr(last), ctypes.c_void_p(stream)), "zk_halo2_lookup_product_device")
+    return last
+
+
+def inner_product(field, a, b, stream=0):
+    out = np.zeros(4, dtype=np.uint64)
+    _check(_plib().zk_inner_product_device(field_id(field), _ptr(a), _ptr(b), int(a.shape[0]), _ptr(out), ctypes.c_void_p(stream)),
+           "zk_inner_product_device")
+    return out
+
+
+def vec_fold(field, a, half, c, stream=0):
+    """a[i] += c a[i + half] for i < half"""
+    cc = _np64(c)
+    _check(_plib().zk_vec_fold_device(field_id(field), _ptr(a), half, _ptr(cc), ctypes.c_void_p(stream)), "zk_vec_fold_device")
+    return a
+
+
+def ipa_fold_bases(curve, g, half, u, stream=0):
+    """parallel_generator_collapse: g[i] <- affine(g[i] + [u] g[i + half]); g: device buffer [2 * half, 2 * limbs]"""
+    uu = _np64(u)
+    _check(_plib().zk_ipa_fold_bases_device(curve_id(curve), _ptr(g), half, _ptr(uu), ctypes.c_void_p(stream)), "zk_ipa_fold_bases_device")
+    return g
+
+
+def evaluate_expression(field, program, columns, consts, log_n_ext, rot_scale, out, stream=0):
+    """program: list of ("col", column, rotation) / ("const", i) / ("add",) / ("sub",) / ("mul",) / ("neg",) / ("scale", i)"""
+    ops = (ExprOp * len(program))()
+    for k, o in enumerate(program):
+        ops[k].op = EXPR_CODES[o[0]]
+        ops[k].rot = o[2] if o[0] == "col" else 0
+        ops[k].arg = o[1] if len(o) > 1 else 0
+    cs = _np64(consts).reshape(-1, 4) if len(consts) else np.zeros((1, 4), dtype=np.uint64)
+    _check(_plib().zk_expr_eval_device(field_id(field), ops, len(program), _ptr_array(columns), len(columns), _ptr(cs), len(consts), log_n_ext,
+                                       rot_scale, _ptr(out), ctypes.c_void_p(stream)), "zk_expr_eval_device")
+    return out
+
+
+class IpaProver:
+    """poly/commitment/prover.rs create_proof, the k rounds of the inner-product argument on device buffers.  The caller
+    owns the transcript: `round()` returns L_j, R_j (before the U / W blinding terms) and <p'_hi, b_lo>, <p'_lo, b_hi>;
+    after hashing them into its transcript the caller feeds the challenge to `fold(u_j)`."""
+
+    def __init__(self, curve, d_p, d_b, d_g, stream=0):
+        """d_p, d_b: device buffers [n, 4] (p' coefficients and the powers of x_3, Montgomery); d_g: [n, 2 * limbs] affine
+        generators (a working copy: it is folded in place)"""
+        self.curve, self.field = curve_id(curve), scalar_field(curve)
+        self.p, self.b, self.g, self.stream = d_p, d_b, d_g, stream
+        self.n = int(d_p.shape[0])
+        assert self.n & (self.n - 1) == 0 and int(d_b.shape[0]) == self.n and int(d_g.shape[0]) == self.n
+
+    def round(self):
+        half = self.n // 2
+        lo, hi = Bases(self.curve, device_tensor=self.g[:half], n=half), Bases(self.curve, device_tensor=self.g[half:self.n], n=half)
+        tl = msm_submit(lo, self.p[half:self.n], montgomery=True, stream=self.stream)          # L = <p'_hi, G'_lo>
+        tr = msm_submit(hi, self.p[:half], montgomery=True, stream=self.stream)                # R = <p'_lo, G'_hi>
+        vl = inner_product(self.field, self.p[half:self.n], self.b[:half], stream=self.stream)
+        vr = inner_product(self.field, self.p[:half], self.b[half:self.n], stream=self.stream)
+        L, R = tl.collect(), tr.collect()
+        lo.free()
+        hi.free()
+        return L, R, vl, vr
+
+    def fold(self, u):
+        half = self.n // 2
+        vec_fold(self.field, self.p, half, field_inverse(self.field, u), stream=self.stream)
+        vec_fold(self.field, self.b, half, u, stream=self.stream)
+        ipa_fold_bases(self.curve, self.g, half, u, stream=self.stream)
+        self.n = half

@@ -64,6 +64,95 @@ int zk_ark_proof_size(zk_pairing_t p);
 int zk_ark_proof_encode(zk_pairing_t p, const void *a_g1_affine_mont, const void *b_g2_affine_mont, const void *c_g1_affine_mont, uint8_t *out);
 int zk_ark_proof_decode(zk_pairing_t p, const uint8_t *in, void *a_g1_affine_mont, void *b_g2_affine_mont, void *c_g1_affine_mont);
 
+/* ---- Groth16 around the MSM / NTT path (ark-groth16 0.3 create_proof; call sites
+ * lib/src/zk/encryption.rs:76, verifiable_encryption.rs:92, sample_entries.rs:86, property.rs:133) ----
+ *
+ * R1CS matrices (ark-relations 0.3 ConstraintMatrices { a, b, c }: one Vec<(coeff, variable index)> per constraint) are
+ * fixed per circuit like the proving key: uploaded once in CSR form (row_ptr: n_rows + 1 offsets; col_idx / val per term,
+ * val in Montgomery form), resident on the home device. */
+int zk_r1cs_matrix_upload(zk_field_t f, const uint64_t *row_ptr_host, const uint32_t *col_idx_host, const void *val_mont_host,
+                          uint64_t n_rows, uint64_t n_cols, uint64_t *handle_out);
+int zk_r1cs_matrix_free(uint64_t handle);
+/* out[i] = <row i, z> for i < n_rows, 0 for n_rows <= i < out_len  (upstream: evaluate_constraint per row) */
+int zk_r1cs_matvec_device(uint64_t matrix, const void *z_mont_dev, void *out_mont_dev, uint64_t out_len, void *hip_stream);
+/* R1CStoQAP::witness_map from the full assignment z (instance variables first, z[0] = 1), all in HBM:
+ *   a = A z, b = B z, c = C z on the first num_constraints rows; a[num_constraints + j] = z[j] for j < num_inputs;
+ *   then the seven NTTs and the pointwise glue of zk_groth16_witness_map_device.  a_dev / b_dev / c_dev are caller
+ *   buffers of 2^log_m elements; on return a_dev holds h.  All three matrices must have the same number of rows
+ *   and num_constraints + num_inputs <= 2^log_m. */
+int zk_groth16_witness_map_r1cs_device(zk_field_t f, uint64_t matrix_a, uint64_t matrix_b, uint64_t matrix_c, const void *z_mont_dev,
+                                       uint64_t num_inputs, uint32_t log_m, void *a_dev, void *b_dev, void *c_dev, void *hip_stream);
+
+/* The last step of create_proof: the proof from the five MSM results, the key's single elements and the blinding r, s.
+ *   A = a_query[0] + a_acc + alpha_g1 + r delta_g1
+ *   B = b_g2_query[0] + b_g2_acc + beta_g2 + s delta_g2          (B1 likewise in G1, used for C only)
+ *   C = s A + r B1 - r s delta_g1 + l_acc + h_acc
+ * Points of the key are affine (x, y) Montgomery; the *_acc are the Jacobian outputs of zk_msm* over query[1..] ; r, s are
+ * Fr elements in Montgomery form.  Host arithmetic (a handful of scalar multiplications), like upstream. */
+typedef struct {
+    const void *alpha_g1, *beta_g1, *delta_g1;
+    const void *beta_g2, *delta_g2;
+    const void *a_query0, *b_g1_query0, *b_g2_query0;
+    const void *a_acc, *b_g1_acc, *l_acc, *h_acc;
+    const void *b_g2_acc;
+    const void *r, *s;
+} zk_groth16_assembly;
+int zk_groth16_assemble_proof(zk_pairing_t p, const zk_groth16_assembly *in, void *a_g1_affine_out, void *b_g2_affine_out,
+                              void *c_g1_affine_out);
+
+/* ---- halo2_proofs 0.2 prover steps beyond commit / FFT, device buffers, Montgomery elements ----
+ * The reference's circuit (circuits-halo2/src/encryption.rs:83-161: 13 advice + 8 fixed columns, a lookup table, a
+ * permutation over the equality-enabled columns) is the shape donor; these are the per-row products a create_proof over
+ * it runs between the column commitments and the opening.  Blinding rows / scalars and the transcript stay with the
+ * caller (RNG and hashing on the CPU), like upstream's structure. */
+
+/* arithmetic.rs BatchInvert: a[i] <- 1 / a[i], zeros stay zero */
+int zk_batch_invert_device(zk_field_t f, void *a_dev, uint64_t n, void *hip_stream);
+/* out[i] = first * prod_{j < i} in[j] (in == out allowed); first NULL = 1; total_out_host (optional, synchronises) =
+ * first * prod of all -- the running value the next chunk of a permutation argument starts from */
+int zk_prefix_product_device(zk_field_t f, const void *in_dev, void *out_dev, uint64_t n, const void *first_mont_host,
+                             void *total_out_mont_host, void *hip_stream);
+/* plonk/permutation/prover.rs Argument::commit, one chunk of <= 8 columns (chunk_len = degree - 2) on the 2^k-row domain:
+ *   Z(0) = z_first (NULL = 1);  Z(i + 1) = Z(i) prod_c (v_c(i) + beta delta^(first_column_index + c) omega^i + gamma)
+ *                                              / prod_c (v_c(i) + beta sigma_c(i) + gamma)
+ * columns_dev / sigmas_dev: host arrays of ncols device pointers (Lagrange form).  z_out_dev gets Z(0 .. 2^k);
+ * z_last_out_host (optional, synchronises) the value after the last row. */
+int zk_halo2_permutation_product_device(zk_field_t f, uint32_t ncols, const void *const *columns_dev, const void *const *sigmas_dev,
+                                        uint32_t first_column_index, const void *beta, const void *gamma, const void *delta, uint32_t k,
+                                        const void *z_first, void *z_out_dev, void *z_last_out_host, void *hip_stream);
+/* plonk/lookup/prover.rs commit_product: Z(0) = 1, Z(i + 1) = Z(i) (A_i + beta)(S_i + gamma) / ((A'_i + beta)(S'_i + gamma));
+ * A', S' are the permuted input / table expressions (permute_expression_pair: a sort, left to the caller) */
+int zk_halo2_lookup_product_device(zk_field_t f, const void *a_dev, const void *s_dev, const void *a_perm_dev, const void *s_perm_dev,
+                                   const void *beta, const void *gamma, uint64_t n, void *z_out_dev, void *z_last_out_host, void *hip_stream);
+/* poly/commitment/prover.rs create_proof, the scalar side of one round: compute_inner_product, and the folds
+ * p'[i] += u^-1 p'[i + half], b[i] += u b[i + half] as a[i] += c a[i + half] */
+int zk_inner_product_device(zk_field_t f, const void *a_dev, const void *b_dev, uint64_t n, void *out_mont_host, void *hip_stream);
+int zk_vec_fold_device(zk_field_t f, void *a_dev, uint64_t half, const void *c_mont_host, void *hip_stream);
+/* ... and the generator side (parallel_generator_collapse): g[i] <- affine(g[i] + [u] g[i + half]), i < half; g holds
+ * 2 * half affine points (x, y) Montgomery on the device, u an element of the curve's scalar field (Montgomery, host) */
+int zk_ipa_fold_bases_device(zk_curve_t c, void *g_affine_dev, uint64_t half, const void *u_mont_host, void *hip_stream);
+
+/* The quotient numerator: one stack program evaluated at every row of the extended domain (plonk/prover.rs: each gate's
+ * Expression over advice / fixed / instance columns with rotations, folded with y).  A rotation by r rows is a shift of
+ * r * rot_scale positions (rot_scale = 2^(extended_k - k)), cyclic.  The program must leave exactly one value; it is
+ * validated on the host (operand indices, stack depth <= 8, <= 512 ops, <= 64 columns, <= 32 constants). */
+typedef struct {
+    uint8_t op;     /* ZK_EXPR_* */
+    uint8_t pad;
+    int16_t rot;    /* ZK_EXPR_COL: rotation in rows */
+    uint32_t arg;   /* ZK_EXPR_COL: column index; ZK_EXPR_CONST / ZK_EXPR_SCALE: constant index */
+} zk_expr_op;
+#define ZK_EXPR_COL 0
+#define ZK_EXPR_CONST 1
+#define ZK_EXPR_ADD 2
+#define ZK_EXPR_SUB 3
+#define ZK_EXPR_MUL 4
+#define ZK_EXPR_NEG 5
+#define ZK_EXPR_SCALE 6
+int zk_expr_eval_device(zk_field_t f, const zk_expr_op *program_host, uint32_t n_ops, const void *const *columns_dev, uint32_t n_columns,
+                        const void *consts_mont_host, uint32_t n_consts, uint32_t log_n_ext, uint32_t rot_scale, void *out_dev,
+                        void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+"""TEST INFRASTRUCTURE -- pure-Python restatement of the halo2_proofs 0.2 prover steps beyond commit / FFT,
+on Python ints and the affine curve arithmetic of oracle/pyref.py.  PARITY UNPINNED (published algorithm; the reference's
+halo2 crate only runs MockProver, circuits-halo2/src/encryption.rs:335, and holds no vectors).
+
+  arithmetic.rs            BatchInvert (0 stays 0), compute_inner_product
+  plonk/permutation/prover.rs  Argument::commit: the grand product Z of one chunk of columns
+        Z(0) = last Z of the previous chunk (1 for the first);  Z(i+1) = Z(i) * prod_col (v + beta delta^col omega^i + gamma)
+                                                                          / prod_col (v + beta sigma_col(omega^i) + gamma)
+  plonk/lookup/prover.rs   commit_product: Z(i+1) = Z(i) (A + beta)(S + gamma) / ((A' + beta)(S' + gamma))
+  poly/commitment/prover.rs create_proof, the argument's k rounds:
+        L_j = <p'_hi, G'_lo>, R_j = <p'_lo, G'_hi>, value_l = <p'_hi, b_lo>, value_r = <p'_lo, b_hi>   (before the U / W blinding terms)
+        fold: p'_i += u^-1 p'_(i+half) ; b_i += u b_(i+half) ; G'_i += [u] G'_(i+half)
+Blinding rows / scalars and the transcript belong to the caller (RNG and hashing stay on the CPU).
+"""
+try:
+    from . import pyref
+except ImportError:
+    import pyref
+
+
+def batch_invert(field, a):
+    p = pyref.FIELDS[field][0]
+    return [pow(x, -1, p) if x else 0 for x in a]
+
+
+def prefix_product(field, f, first=1):
+    """z[0] = first, z[i+1] = z[i] f[i]  -> (z of len(f) entries, product of everything)"""
+    p = pyref.FIELDS[field][0]
+    z, cur = [], first % p
+    for x in f:
+        z.append(cur)
+        cur = cur * x % p
+    return z, cur
+
+
+def permutation_factors(field, columns, sigmas, beta, gamma, delta, omega, first_col):
+    """per row: numerator / denominator of one chunk (columns first_col .. first_col + len(columns))"""
+    p = pyref.FIELDS[field][0]
+    n = len(columns[0])
+    num, den = [1] * n, [1] * n
+    for c, (v, s) in enumerate(zip(columns, sigmas)):
+        dc = pow(delta, first_col + c, p) * beta % p
+        w = 1
+        for i in range(n):
+            num[i] = num[i] * ((v[i] + dc * w + gamma) % p) % p
+            den[i] = den[i] * ((v[i] + beta * s[i] + gamma) % p) % p
+            w = w * omega % p
+    inv = batch_invert(field, den)
+    return [a * b % p for a, b in zip(num, inv)]
+
+
+def lookup_factors(field, A, S, Ap, Sp, beta, gamma):
+    p = pyref.FIELDS[field][0]
+    den = batch_invert(field, [((a + beta) * (s + gamma)) % p for a, s in zip(Ap, Sp)])
+    return [(a + beta) * (s + gamma) % p * d % p for a, s, d in zip(A, S, den)]
+
+
+def inner_product(field, a, b):
+    p = pyref.FIELDS[field][0]
+    return sum(x * y for x, y in zip(a, b)) % p
+
+
+def ipa_round(curve, p_prime, b, g):
+    """-> (L, R, value_l, value_r) of one round on vectors of length 2 * half; points as pyref affine tuples / None"""
+    sf = pyref.CURVES[curve][1]
+    half = len(p_prime) // 2
+    L = pyref.msm_naive(curve, p_prime[half:], g[:half])
+    R = pyref.msm_naive(curve, p_prime[:half], g[half:])
+    return L, R, inner_product(sf, p_prime[half:], b[:half]), inner_product(sf, p_prime[:half], b[half:])
+
+
+def ipa_fold(curve, p_prime, b, g, u):
+    sf = pyref.CURVES[curve][1]
+    r = pyref.FIELDS[sf][0]
+    half = len(p_prime) // 2
+    ui = pow(u, -1, r)
+    p2 = [(p_prime[i] + p_prime[i + half] * ui) % r for i in range(half)]
+    b2 = [(b[i] + b[i + half] * u) % r for i in range(half)]
+    g2 = [pyref.ec_add(curve, g[i], pyref.ec_mul(curve, u, g[i + half])) for i in range(half)]
+    return p2, b2, g2
+
+
+def ipa_argument(curve, p_prime, b, g, challenges):
+    """all k rounds with the given challenges -> ([(L, R, value_l, value_r)], final c = p'[0], final b, final G)"""
+    rounds = []
+    for u in challenges:
+        rounds.append(ipa_round(curve, p_prime, b, g))
+        p_prime, b, g = ipa_fold(curve, p_prime, b, g, u)
+    assert len(p_prime) == 1
+    return rounds, p_prime[0], b[0], g[0]
+
+
+def eval_program(field, program, columns, consts, n_ext, rot_scale, i):
+    """the quotient evaluator's stack program at row i of the extended domain (see include/zkcp_amd_prover.h, zk_expr_*):
+    ops: ("col", column, rotation) ("const", index) ("add",) ("sub",) ("mul",) ("neg",) ("scale", index)"""
+    p = pyref.FIELDS[field][0]
+    st = []
+    for op in program:
+        if op[0] == "col":
+            st.append(columns[op[1]][(i + op[2] * rot_scale) % n_ext])
+        elif op[0] == "const":
+            st.append(consts[op[1]] % p)
+        elif op[0] == "neg":
+            st.append((-st.pop()) % p)
+        elif op[0] == "scale":
+            st.append(st.pop() * consts[op[1]] % p)
+        else:
+            y, x = st.pop(), st.pop()
+            st.append((x + y) % p if op[0] == "add" else (x - y) % p if op[0] == "sub" else x * y % p)
+    assert len(st) == 1
+    return st[0]

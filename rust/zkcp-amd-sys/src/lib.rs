@@ -107,6 +107,34 @@ pub struct zk_ark_pk_index {
     pub total_bytes: u64,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zk_groth16_assembly {
+    pub alpha_g1: *const c_void,
+    pub beta_g1: *const c_void,
+    pub delta_g1: *const c_void,
+    pub beta_g2: *const c_void,
+    pub delta_g2: *const c_void,
+    pub a_query0: *const c_void,
+    pub b_g1_query0: *const c_void,
+    pub b_g2_query0: *const c_void,
+    pub a_acc: *const c_void,
+    pub b_g1_acc: *const c_void,
+    pub l_acc: *const c_void,
+    pub h_acc: *const c_void,
+    pub b_g2_acc: *const c_void,
+    pub r: *const c_void,
+    pub s: *const c_void,
+}
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct zk_expr_op {
+    pub op: u8,
+    pub pad: u8,
+    pub rot: i16,
+    pub arg: u32,
+}
+
 extern "C" {
     // ---- include/zkcp_amd.h
     pub fn zk_init(device_id: c_int) -> c_int;
@@ -178,6 +206,32 @@ extern "C" {
                                c_g1_affine_mont: *const c_void, out: *mut u8) -> c_int;
     pub fn zk_ark_proof_decode(p: c_int, input: *const u8, a_g1_affine_mont: *mut c_void, b_g2_affine_mont: *mut c_void,
                                c_g1_affine_mont: *mut c_void) -> c_int;
+    pub fn zk_r1cs_matrix_upload(f: c_int, row_ptr_host: *const u64, col_idx_host: *const u32, val_mont_host: *const c_void, n_rows: u64,
+                                 n_cols: u64, handle_out: *mut u64) -> c_int;
+    pub fn zk_r1cs_matrix_free(handle: u64) -> c_int;
+    pub fn zk_r1cs_matvec_device(matrix: u64, z_mont_dev: *const c_void, out_mont_dev: *mut c_void, out_len: u64, hip_stream: *mut c_void) -> c_int;
+    pub fn zk_groth16_witness_map_r1cs_device(f: c_int, matrix_a: u64, matrix_b: u64, matrix_c: u64, z_mont_dev: *const c_void,
+                                              num_inputs: u64, log_m: u32, a_dev: *mut c_void, b_dev: *mut c_void, c_dev: *mut c_void,
+                                              hip_stream: *mut c_void) -> c_int;
+    pub fn zk_groth16_assemble_proof(p: c_int, input: *const zk_groth16_assembly, a_g1_affine_out: *mut c_void, b_g2_affine_out: *mut c_void,
+                                     c_g1_affine_out: *mut c_void) -> c_int;
+    pub fn zk_batch_invert_device(f: c_int, a_dev: *mut c_void, n: u64, hip_stream: *mut c_void) -> c_int;
+    pub fn zk_prefix_product_device(f: c_int, in_dev: *const c_void, out_dev: *mut c_void, n: u64, first_mont_host: *const c_void,
+                                    total_out_mont_host: *mut c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn zk_halo2_permutation_product_device(f: c_int, ncols: u32, columns_dev: *const *const c_void, sigmas_dev: *const *const c_void,
+                                               first_column_index: u32, beta: *const c_void, gamma: *const c_void, delta: *const c_void, k: u32,
+                                               z_first: *const c_void, z_out_dev: *mut c_void, z_last_out_host: *mut c_void,
+                                               hip_stream: *mut c_void) -> c_int;
+    pub fn zk_halo2_lookup_product_device(f: c_int, a_dev: *const c_void, s_dev: *const c_void, a_perm_dev: *const c_void,
+                                          s_perm_dev: *const c_void, beta: *const c_void, gamma: *const c_void, n: u64, z_out_dev: *mut c_void,
+                                          z_last_out_host: *mut c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn zk_inner_product_device(f: c_int, a_dev: *const c_void, b_dev: *const c_void, n: u64, out_mont_host: *mut c_void,
+                                   hip_stream: *mut c_void) -> c_int;
+    pub fn zk_vec_fold_device(f: c_int, a_dev: *mut c_void, half: u64, c_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn zk_ipa_fold_bases_device(c: c_int, g_affine_dev: *mut c_void, half: u64, u_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn zk_expr_eval_device(f: c_int, program_host: *const zk_expr_op, n_ops: u32, columns_dev: *const *const c_void, n_columns: u32,
+                               consts_mont_host: *const c_void, n_consts: u32, log_n_ext: u32, rot_scale: u32, out_dev: *mut c_void,
+                               hip_stream: *mut c_void) -> c_int;
 }
 
 // =====================================================================================================================

@@ -515,3 +515,202 @@ def check_halo2_domain(zk, name, k, j=9):
     got_back = to_host(zk, dom.extended_to_coeff(to_device(zk, exp_ext)))
     assert (got_back == back).all(), (name, k, "extended_to_coeff")
     assert (got_back == padded).all()
+
+
+# ------------------------------------------------------------------ Groth16 end to end (a1 / a6): toy R1CS, known trapdoor
+def check_groth16_prove(zk, pairing, seed=5, num_constraints=40, long_rows=(17,), num_inputs=3):
+    """The whole device-side create_proof -- CSR mat-vecs, witness map, five MSMs over a key read from the reference's
+    serialize_unchecked bytes, assembly, ark_to_bytes(proof) -- against the pure-Python Groth16-in-the-exponent reference
+    (oracle/pyref_groth16.py): A, B, C must equal [a]G1, [b]G2, [c]G1 and satisfy the verification identity."""
+    from oracle import pyref_groth16 as g16
+    az = zk.ark_serialize
+    field = "Bls381Fr" if pairing == "Bls381" else "Bn254Fr"
+    g1, g2 = az.PAIRING_CURVES[az.pairing_id(pairing)]
+    p = pyref.FIELDS[field][0]
+    r1cs, z = g16.random_r1cs(field, seed, num_inputs=num_inputs, num_constraints=num_constraints, long_rows=long_rows)
+    key = g16.setup(r1cs, seed + 100)
+    m, nvars = key["m"], len(z)
+    pts = lambda curve, logs: orc.fixed_base_mul(curve, orc.ints_to_array([v % p for v in logs], 4), threads=8)
+    one = lambda curve, v: pts(curve, [v])
+    members = {"alpha_g1": one(g1, key["alpha"]), "beta_g2": one(g2, key["beta"]), "gamma_g2": one(g2, key["gamma"]),
+               "delta_g2": one(g2, key["delta"]), "gamma_abc_g1": pts(g1, key["gamma_abc"]), "beta_g1": one(g1, key["beta"]),
+               "delta_g1": one(g1, key["delta"]), "a_query": pts(g1, key["a_query"]), "b_g1_query": pts(g1, key["b_query"]),
+               "b_g2_query": pts(g2, key["b_query"]), "h_query": pts(g1, key["h_query"]), "l_query": pts(g1, key["l_query"])}
+    pk = az.ProvingKey.deserialize_unchecked(pairing, az.ProvingKey.serialize_unchecked(pairing, members))   # through the wire format
+    mont = lambda v: orc.int_to_limbs(pyref.mont(field, v % p), 4)
+    mats = [zk.groth16.R1csMatrix(field, [[(mont(c), j) for c, j in row] for row in r1cs[k]], n_cols=nvars) for k in "ABC"]
+    z_mont = np.stack([mont(v) for v in z])
+    # the mat-vecs alone, then the witness map, against the reference's evaluations / quotient
+    ea, eb, ec = g16.evaluations(r1cs, z)
+    d_z = to_device(zk, z_mont)
+    for mtx, exp in zip(mats, (ea, eb, ec)):
+        got = to_host(zk, mtx.matvec(d_z, to_device(zk, np.ones((m, 4), dtype=np.uint64))))
+        exp = list(exp)
+        if mtx is mats[0]:
+            for j in range(num_inputs):
+                exp[len(r1cs["A"]) + j] = 0          # the input-consistency rows are added by the witness map, not by the matrix
+        assert (got == np.stack([mont(v) for v in exp])).all()
+    h_exp = np.stack([mont(v) for v in g16.h_coefficients(r1cs, z)])
+    bufs = [to_device(zk, np.zeros((m, 4), dtype=np.uint64)) for _ in range(3)]
+    h = to_host(zk, zk.groth16.witness_map(field, mats[0], mats[1], mats[2], d_z, num_inputs, *bufs))
+    assert (h == h_exp).all(), "witness map"
+    # the proof
+    prover = zk.groth16.Prover(pairing, pk, mats[0], mats[1], mats[2], num_inputs, lambda a: to_device(zk, a))
+    rng = pyref.Rng(seed + 200)
+    for r, s in ((rng.below(p), rng.below(p)), (0, 0), (1, p - 1)):
+        (A, B, C), proof_bytes = prover.prove(z_mont, mont(r), mont(s))
+        a, b, c = g16.prove_logs(r1cs, key, z, r, s)
+        assert g16.verify_logs(r1cs, key, z[:num_inputs], a, b, c)
+        assert (A == one(g1, a)[0]).all() and (B == one(g2, b)[0]).all() and (C == one(g1, c)[0]).all(), (pairing, r, s)
+        dA, dB, dC = az.proof_from_bytes(pairing, proof_bytes)            # what the reference's `buy` would deserialize
+        assert (dA == A).all() and (dB == B).all() and (dC == C).all()
+        assert len(proof_bytes) == (192 if pairing == "Bls381" else 128)
+    # a wrong witness gives a proof that does NOT verify (the quotient no longer divides): the path takes no shortcut
+    bad = list(z)
+    bad[-1] = (bad[-1] + 1) % p
+    (A2, _, _), _ = prover.prove(np.stack([mont(v) for v in bad]), mont(3), mont(4))
+    assert not (A2 == A).all()
+    prover.free()
+
+
+# ------------------------------------------------------------------ halo2 prover steps beyond commit / FFT (f4)
+def _ints(name, arr):
+    return orc.array_to_ints(orc.from_mont(name, np.ascontiguousarray(arr)))
+
+
+def _monts(name, ints):
+    p = pyref.FIELDS[name][0]
+    return orc.to_mont(name, orc.ints_to_array([v % p for v in ints], 4)) if len(ints) else np.zeros((0, 4), dtype=np.uint64)
+
+
+def check_batch_invert_and_scan(zk, name, n, seed=3):
+    from oracle import pyref_halo2 as h2
+    p = pyref.FIELDS[name][0]
+    a = rand_field(name, n, seed)
+    if n > 5:
+        a[3] = 0
+        a[n - 1] = 0                                   # zeros stay zero
+    ai = _ints(name, a)
+    got = to_host(zk, zk.halo2.batch_invert(name, to_device(zk, a)))
+    assert (got == _monts(name, h2.batch_invert(name, ai))).all(), (name, n, "batch_invert")
+    f = rand_field(name, n, seed + 1)
+    first = rand_field(name, 1, seed + 2)[0]
+    z, tot = h2.prefix_product(name, _ints(name, f), _ints(name, first.reshape(1, 4))[0])
+    out, total = zk.halo2.prefix_product(name, to_device(zk, f), first=first, want_total=True)
+    assert (to_host(zk, out) == _monts(name, z)).all(), (name, n, "prefix_product")
+    assert (total == _monts(name, [tot])[0]).all()
+    out2 = to_device(zk, np.zeros((n, 4), dtype=np.uint64))
+    zk.halo2.prefix_product(name, to_device(zk, f), out=out2)
+    z1, _ = h2.prefix_product(name, _ints(name, f))
+    assert (to_host(zk, out2) == _monts(name, z1)).all()
+
+
+def check_permutation_and_lookup_products(zk, name, k, ncols=5, seed=9):
+    """the grand products of halo2's permutation argument (two chunks, the second continuing from the first) and lookup
+    argument against the pure-Python restatement; for a genuine permutation / lookup the final value is 1"""
+    from oracle import pyref_halo2 as h2
+    p = pyref.FIELDS[name][0]
+    n = 1 << k
+    rng = pyref.Rng(seed)
+    omega = pyref.root_of_unity(name, k)
+    delta = pow(pyref.FIELDS[name][1], 1 << pyref.two_adicity(p)[0], p)      # halo2's DELTA = generator^(2^S): order t, outside the 2^S subgroup
+    # a genuine copy-constraint system: values constant on the cycles of a random permutation of the (column, row) cells
+    cells = [(c, i) for c in range(ncols) for i in range(n)]
+    perm = list(range(len(cells)))
+    for i in range(len(perm) - 1, 0, -1):
+        j = rng.below(i + 1)
+        perm[i], perm[j] = perm[j], perm[i]
+    val, seen = [None] * len(cells), [False] * len(cells)
+    for s0 in range(len(cells)):
+        if not seen[s0]:
+            v, t = rng.below(p), s0
+            while not seen[t]:
+                seen[t], val[t] = True, v
+                t = perm[t]
+    cols = [[val[c * n + i] for i in range(n)] for c in range(ncols)]
+    label = lambda c, i: pow(delta, c, p) * pow(omega, i, p) % p
+    sig = [[label(*cells[perm[c * n + i]]) for i in range(n)] for c in range(ncols)]
+    beta, gamma = rng.below(p), rng.below(p)
+    chunks = [(0, 3), (3, ncols)]
+    zf, d_cols, d_sig = None, [to_device(zk, _monts(name, c)) for c in cols], [to_device(zk, _monts(name, s)) for s in sig]
+    last_exp = 1
+    for lo, hi in chunks:
+        f = h2.permutation_factors(name, cols[lo:hi], sig[lo:hi], beta, gamma, delta, omega, lo)
+        z_exp, last_exp = h2.prefix_product(name, f, last_exp)
+        z_out = to_device(zk, np.zeros((n, 4), dtype=np.uint64))
+        zf = zk.halo2.permutation_product(name, d_cols[lo:hi], d_sig[lo:hi], _monts(name, [beta])[0], _monts(name, [gamma])[0],
+                                          _monts(name, [delta])[0], k, z_out, first_column_index=lo, z_first=zf)
+        assert (to_host(zk, z_out) == _monts(name, z_exp)).all(), (name, k, lo)
+        assert (zf == _monts(name, [last_exp])[0]).all()
+    assert last_exp == 1, "a genuine permutation closes the product"
+    # lookup: A' a permutation of A, S' of S with A'_i in {S'_i, A'_(i-1)} -- here the products only need multiset equality
+    A = [rng.below(64) for _ in range(n)]
+    S = list(range(64)) + [rng.below(64) for _ in range(n - 64)] if n >= 64 else [rng.below(p) for _ in range(n)]
+    Ap, Sp = sorted(A), sorted(S)
+    fexp = h2.lookup_factors(name, A, S, Ap, Sp, beta, gamma)
+    z_exp, last = h2.prefix_product(name, fexp)
+    z_out = to_device(zk, np.zeros((n, 4), dtype=np.uint64))
+    got_last = zk.halo2.lookup_product(name, *[to_device(zk, _monts(name, v)) for v in (A, S, Ap, Sp)], _monts(name, [beta])[0],
+                                       _monts(name, [gamma])[0], z_out)
+    assert (to_host(zk, z_out) == _monts(name, z_exp)).all() and (got_last == _monts(name, [last])[0]).all()
+    assert last == 1
+
+
+def check_ipa(zk, cname, k, seed=13):
+    """halo2_proofs 0.2 inner-product argument rounds on the device (two MSMs, two inner products, three folds per round)
+    against the pure-Python restatement; the folded generator equals <s, G> with s_i = prod_j u_j^(bit_j(i))"""
+    from oracle import pyref_halo2 as h2
+    sf = pyref.CURVES[cname][1]
+    r = pyref.FIELDS[sf][0]
+    n = 1 << k
+    rng = pyref.Rng(seed)
+    gens = bases_for(cname, n, seed=31)
+    L = orc.coord_limbs(cname)
+    bf = pyref.CURVES[cname][0]
+    unm = lambda row: tuple(orc.limbs_to_int(orc.from_mont(bf, row[j * L:(j + 1) * L].reshape(1, L))[0]) for j in range(2))
+    g_py = [unm(gens[i]) for i in range(n)]
+    pp = [rng.below(r) for _ in range(n)]
+    x3 = rng.below(r)
+    b = [pow(x3, i, r) for i in range(n)]
+    us = [1 + rng.below(r - 1) for _ in range(k)]
+    rounds, c_fin, b_fin, g_fin = h2.ipa_argument(cname, pp, b, g_py, us)
+    ipa = zk.halo2.IpaProver(cname, to_device(zk, _monts(sf, pp)), to_device(zk, _monts(sf, b)), to_device(zk, gens.copy()))
+    aff = lambda P: np.zeros(2 * L, dtype=np.uint64) if P is None else np.concatenate([orc.int_to_limbs(pyref.mont(bf, c), L) for c in P])
+    for j in range(k):
+        Lj, Rj, vl, vr = ipa.round()
+        eL, eR, evl, evr = rounds[j]
+        assert (zk.point_to_affine(cname, Lj) == aff(eL)).all() and (zk.point_to_affine(cname, Rj) == aff(eR)).all(), (cname, k, j)
+        assert (vl == _monts(sf, [evl])[0]).all() and (vr == _monts(sf, [evr])[0]).all()
+        ipa.fold(_monts(sf, [us[j]])[0])
+    assert (to_host(zk, ipa.p)[0] == _monts(sf, [c_fin])[0]).all() and (to_host(zk, ipa.b)[0] == _monts(sf, [b_fin])[0]).all()
+    assert (to_host(zk, ipa.g)[0] == aff(g_fin)).all()
+
+
+def check_expression(zk, name, k, ext=2, seed=21):
+    """the quotient-numerator evaluator: a small gate set in the style of the reference's circuit (a multiplication gate
+    behind a selector, a Pow5-style S-box with a rotation, a boolean check), folded with y, over extended-domain columns"""
+    from oracle import pyref_halo2 as h2
+    p = pyref.FIELDS[name][0]
+    ek = k + ext
+    ne, scale = 1 << ek, 1 << ext
+    cols = [rand_field(name, ne, seed + c) for c in range(5)]          # a, b, c, q_mul, q_pow on the extended domain
+    ci = [_ints(name, c) for c in cols]
+    y = 0x1234567 % p
+    consts = [y, 5, 1]
+    a, b, c, qm, qp = (("col", i, 0) for i in range(5))
+    prog = [qm, a, b, ("mul",), c, ("sub",), ("mul",),                                 # q_mul (a b - c)
+            ("scale", 0),                                                               # * y
+            qp, a, a, ("mul",), a, ("mul",), a, ("mul",), a, ("mul",), ("col", 1, 1), ("sub",), ("const", 1), ("add",), ("mul",),   # q_pow (a^5 - b(omega X) + 5)
+            ("add",), ("scale", 0),
+            c, c, ("const", 2), ("sub",), ("mul",), ("add",),                          # c (c - 1)
+            ("col", 0, -3), ("neg",), ("add",)]                                         # - a(omega^-3 X)
+    exp = [h2.eval_program(name, prog, ci, consts, ne, scale, i) for i in range(ne)]
+    out = to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
+    zk.halo2.evaluate_expression(name, prog, [to_device(zk, c) for c in cols], _monts(name, consts), ek, scale, out)
+    assert (to_host(zk, out) == _monts(name, exp)).all(), (name, k)
+    for bad in ([("add",)], [a, b], [("col", 9, 0)], [("const", 7)], [a] * 9 + [("add",)] * 8):   # malformed programs are refused on the host
+        try:
+            zk.halo2.evaluate_expression(name, bad, [to_device(zk, c) for c in cols], _monts(name, consts), ek, scale, out)
+            raise AssertionError("accepted " + repr(bad))
+        except zk.ZkError:
+            pass

@@ -148,3 +148,23 @@ def test_halo2_domain(zk):
     ps.check_halo2_domain(zk, "PallasFp", 5)          # degree-9 gates: extended_k = k + 3
     ps.check_halo2_domain(zk, "PallasFq", 4, j=5)     # extended_k = k + 2
     ps.check_halo2_domain(zk, "PallasFp", 3, j=2)     # nothing to extend
+
+
+def test_groth16_prove_end_to_end(zk):
+    ps.check_groth16_prove(zk, "Bls381", num_constraints=26, long_rows=(20,))      # domain 32; one row of > 20 terms
+
+
+def test_halo2_products(zk):
+    ps.check_batch_invert_and_scan(zk, "PallasFp", 5000)       # two scan workgroups, a ragged tail
+    ps.check_batch_invert_and_scan(zk, "Bls381Fr", 37)
+    ps.check_batch_invert_and_scan(zk, "PallasFq", 1)
+    ps.check_permutation_and_lookup_products(zk, "PallasFp", 6)
+
+
+def test_halo2_ipa(zk):
+    ps.check_ipa(zk, "Vesta", 4)
+    ps.check_ipa(zk, "Pallas", 2)
+
+
+def test_halo2_expression(zk):
+    ps.check_expression(zk, "PallasFp", 4)

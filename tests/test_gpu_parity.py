@@ -466,3 +466,62 @@ def test_proving_key_file_to_resident_bases(zk, pairing, g1, g2):
     got = zk.point_to_affine(g1, zk.msm(tail, sc[1:]))
     assert (got == orc.msm_ark(g1, a_q[1:], sc[1:], threads=8)).all()
     tail.free()
+
+
+@pytest.mark.parametrize("pairing,nc,long_rows", [("Bls381", 120, (70, 110)), ("Bn254", 60, (40,))])
+def test_groth16_prove_end_to_end(zk, pairing, nc, long_rows):
+    """a1 + a6: assignment -> proof bytes entirely through the library (the reference's call: lib/src/zk/encryption.rs:76),
+    checked against Groth16 in the exponent; long rows (> 64 terms) take the workgroup-per-row mat-vec kernel"""
+    ps.check_groth16_prove(zk, pairing, num_constraints=nc, long_rows=long_rows)
+
+
+# ------------------------------------------------------------------ halo2 prover steps beyond commit / FFT (f4)
+@pytest.mark.parametrize("name,n", [("PallasFp", 1 << 16), ("PallasFq", 70001), ("Bn254Fr", 4097), ("Bls381Fr", 1)])
+def test_halo2_batch_invert_and_scan(zk, name, n):
+    ps.check_batch_invert_and_scan(zk, name, n)
+
+
+@pytest.mark.parametrize("name,k", [("PallasFp", 10), ("PallasFq", 7)])
+def test_halo2_permutation_and_lookup_products(zk, name, k):
+    ps.check_permutation_and_lookup_products(zk, name, k)
+
+
+@pytest.mark.parametrize("cname,k", [("Vesta", 6), ("Pallas", 5)])
+def test_halo2_ipa(zk, cname, k):
+    ps.check_ipa(zk, cname, k)
+
+
+def test_halo2_expression(zk):
+    ps.check_expression(zk, "PallasFp", 8, ext=3)
+
+
+def test_halo2_products_2p20(zk):
+    """the same products at the circuit size of configs[2]: the scan's closing value against Python integers, batch inversion
+    through a * a^-1 = 1, the IPA folds through the size-independent identity fold(fold(a, u), v) on a prefix"""
+    import torch
+    name, n = "PallasFp", 1 << 20
+    from oracle import pyref
+    p = pyref.FIELDS[name][0]
+    f = ps.rand_field(name, n, 77)
+    d = torch.from_numpy(f.view(np.int64)).cuda()
+    out, total = zk.halo2.prefix_product(name, d, want_total=True)
+    ints = orc.array_to_ints(orc.from_mont(name, f))
+    acc = 1
+    for v in ints:
+        acc = acc * v % p
+    assert orc.limbs_to_int(orc.from_mont(name, total.reshape(1, 4))[0]) == acc
+    back = out.cpu().numpy().view(np.uint64)
+    assert (back[0] == orc.to_mont(name, orc.ints_to_array([1], 4))[0]).all()
+    pre = 1
+    for i in (1, 2, 4097, n - 1):          # spot checks across block boundaries
+        pre = 1
+        for v in ints[:i]:
+            pre = pre * v % p
+        assert orc.limbs_to_int(orc.from_mont(name, back[i].reshape(1, 4))[0]) == pre
+    a = torch.from_numpy(f.view(np.int64)).cuda()
+    inv = a.clone()
+    zk.halo2.batch_invert(name, inv)
+    zk.vec_op(name, "mul", inv, a)
+    torch.cuda.synchronize()
+    one = orc.to_mont(name, orc.ints_to_array([1], 4))[0]
+    assert (inv.cpu().numpy().view(np.uint64) == one).all()

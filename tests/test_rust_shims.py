@@ -41,12 +41,13 @@ def test_repr_c_structs_match():
     hdr = open(os.path.join(ROOT, "include", "zkcp_amd.h")).read() + open(os.path.join(ROOT, "include", "zkcp_amd_prover.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     rs = open(os.path.join(ROOT, "rust", "zkcp-amd-sys", "src", "lib.rs")).read()
-    for name in ("zk_msm_opts", "zk_ntt_opts", "zk_msm_profile", "zk_msm_totals", "zk_ntt_totals", "zk_ark_span", "zk_ark_pk_index"):
+    for name in ("zk_msm_opts", "zk_ntt_opts", "zk_msm_profile", "zk_msm_totals", "zk_ntt_totals", "zk_ark_span", "zk_ark_pk_index",
+                 "zk_groth16_assembly", "zk_expr_op"):
         body = re.search(r"typedef struct \{([^}]*)\}\s*%s;" % name, hdr, flags=re.S).group(1)
         n_c = 0
         for decl in [d.strip() for d in body.split(";") if d.strip()]:
-            names = decl.split(None, 1)[1] if not decl.startswith("zk_ark_span") else decl[len("zk_ark_span"):]
-            n_c += len([x for x in names.split(",") if x.strip()])
+            decl = re.sub(r"^(const\s+)?(void|zk_ark_span|[a-z0-9_]+_t|int|float|double)\s*", "", decl)
+            n_c += len([x for x in decl.split(",") if x.strip()])
         rbody = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, flags=re.S).group(1)
         n_r = len(re.findall(r"pub [a-z0-9_]+:", rbody))
         assert n_c == n_r, (name, n_c, n_r)
