@@ -66,11 +66,11 @@ int msm_finish_impl(MsmJob& job, void* out_jac) {
     return ZK_OK;
 }
 
-// C: the curve of the ABI call.  CK: the view the kernels compute in.  bases: device array of Affine<CK>.
+// C: the curve of the ABI call.  CK: the view the kernels compute in.  bases: device array of StoredAffine<CK>.
 // Enqueues every kernel of the MSM and the copy of the per-window partial sums on job.stream and returns; no host
 // synchronisation (workspace growth aside).
 template <class C, class CK>
-int msm_enqueue_impl(MsmJob& job, const Affine<CK>* bases, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
+int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
     hipStream_t st = job.stream;
     memset(&job.prof, 0, sizeof job.prof);
     job.finish = &msm_finish_impl<C, CK>;
@@ -296,9 +296,9 @@ int bases_prepare_run(BasesCopy& bc, uint64_t n) {
     if constexpr (has_f29<C>()) {
         if (n == 0) return ZK_OK;
         void* d = nullptr;
-        HIP_TRY(hipMalloc(&d, sizeof(Affine<F29View<C>>) * n));
+        HIP_TRY(hipMalloc(&d, sizeof(StoredAffine<F29View<C>>) * n));
         ZK_LAUNCH((bases_to29_kernel<C>), (unsigned)((n + 255) / 256), 256, 0, (hipStream_t)0, (const Affine<C>*)bc.dev,
-                  (Affine<F29View<C>>*)d, n);
+                  (StoredAffine<F29View<C>>*)d, n);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess) {
             hipFree(d);
             return ZK_ERR_HIP;
@@ -313,7 +313,7 @@ template <class C>
 int msm_enqueue(MsmJob& job, const BasesCopy& bc, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
     if constexpr (has_f29<C>()) {
         if (bc.dev29 && tu.limb_bits != 32)
-            return msm_enqueue_impl<C, F29View<C>>(job, (const Affine<F29View<C>>*)bc.dev29, d_scalars, n, mont, tu);
+            return msm_enqueue_impl<C, F29View<C>>(job, (const StoredAffine<F29View<C>>*)bc.dev29, d_scalars, n, mont, tu);
     }
     return msm_enqueue_impl<C, C>(job, (const Affine<C>*)bc.dev, d_scalars, n, mont, tu);
 }

@@ -528,13 +528,53 @@ struct MsmSeg {
     uint32_t bucket, start, len, big_index;
 };
 
+// How the bases of a kernel view are kept in HBM.  The saturated views read the points as uploaded.  The lazy-limb views
+// keep x R' mod p (a value below 2p) PACKED in the caller's 32-bit words -- 64 B per G1 point (96 B BLS12-381), 128 / 192 B on
+// G2, the size of the uploaded point -- and unpack to 29 / 28-bit limbs in registers (18 shift / mask pairs per point, ~1.5 %
+// of a mixed addition): every window gathers every base once, so the record size is the kernel's HBM / Infinity-Cache
+// traffic (a 64-B record is one aligned fabric request; the 80-B unpacked record straddled two).
+template <class CK>
+struct StoredBase {
+    using type = Affine<CK>;
+};
 template <class C>
-__device__ __forceinline__ void accumulate_slice(XYZZ<C>& acc, const Affine<C>* __restrict__ bases,
+struct StoredBase<C29<C>> {
+    using type = Affine<C>;
+};
+template <class C>
+struct StoredBase<C29x2<C>> {
+    using type = Affine<C>;
+};
+template <class CK>
+using StoredAffine = typename StoredBase<CK>::type;
+
+template <class CK>
+__device__ __forceinline__ void load_base(Affine<CK>& p, const Affine<CK>* __restrict__ bases, uint32_t idx) {
+    p = bases[idx];
+}
+template <class C>
+__device__ __forceinline__ void load_base(Affine<C29<C>>& p, const Affine<C>* __restrict__ bases, uint32_t idx) {
+    const Affine<C> raw = bases[idx];
+    fe29_unpack(p.x, raw.x);
+    fe29_unpack(p.y, raw.y);
+}
+template <class C>
+__device__ __forceinline__ void load_base(Affine<C29x2<C>>& p, const Affine<C>* __restrict__ bases, uint32_t idx) {
+    const Affine<C> raw = bases[idx];
+    fe29_unpack(p.x.c0, raw.x.c0);
+    fe29_unpack(p.x.c1, raw.x.c1);
+    fe29_unpack(p.y.c0, raw.y.c0);
+    fe29_unpack(p.y.c1, raw.y.c1);
+}
+
+template <class C>
+__device__ __forceinline__ void accumulate_slice(XYZZ<C>& acc, const StoredAffine<C>* __restrict__ bases,
                                                  const uint32_t* __restrict__ sorted, uint32_t start, uint32_t cnt,
                                                  uint32_t stride) {
     for (uint32_t k = 0; k < cnt; k += stride) {
         const uint32_t e = sorted[start + k];
-        Affine<C> p = bases[e & 0x7fffffffu];
+        Affine<C> p;
+        load_base(p, bases, e & 0x7fffffffu);
         aff_neg_if(p, (e >> 31) != 0);
         xyzz_add_mixed(acc, p);
     }
@@ -561,7 +601,7 @@ constexpr int msm_acc_waves() {
     return 4;
 }
 template <class C>
-__global__ void __launch_bounds__(64, msm_acc_waves<C>()) msm_accumulate_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(64, msm_acc_waves<C>()) msm_accumulate_kernel(const StoredAffine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                       const uint32_t* __restrict__ offs, const uint32_t* __restrict__ counts,
                                       const uint32_t* __restrict__ order, XYZZ<C>* __restrict__ buckets, MsmShape sh,
                                       MsmQueue* __restrict__ q, MsmSeg* __restrict__ seg_list, uint32_t* __restrict__ big_list) {
@@ -634,7 +674,8 @@ __global__ void __launch_bounds__(64, msm_acc_waves<C>()) msm_accumulate_kernel(
         // ---- one mixed add for every lane that owns a bucket
         if (have) {
             const uint32_t e = sorted[pos];
-            Affine<C> p = bases[e & 0x7fffffffu];
+            Affine<C> p;
+            load_base(p, bases, e & 0x7fffffffu);
             aff_neg_if(p, (e >> 31) != 0);
             xyzz_add_mixed(acc, p);
             if (++pos == end) {
@@ -672,7 +713,7 @@ __global__ void __launch_bounds__(64) msm_combine_sub_kernel(const XYZZ<C>* __re
 // One wave per segment of an oversized bucket: lane-strided partial sums + LDS tree.
 // Fixed grid; waves stride over the device-side segment list.
 template <class C>
-__global__ void __launch_bounds__(64) msm_accumulate_big_kernel(const Affine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(64) msm_accumulate_big_kernel(const StoredAffine<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                                 const MsmQueue* __restrict__ q, const MsmSeg* __restrict__ seg_list,
                                                                 XYZZ<C>* __restrict__ seg_out) {
     __shared__ XYZZ<C> sh[64];
@@ -891,15 +932,30 @@ __global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<C>* __restrict_
     if (tid == 0) out[(uint64_t)s * per_out + o] = acc;
 }
 
-// bases as uploaded (x R, 8 x u32 per coordinate)  ->  the F29 view the bucket kernels use (x R', 9 x 29-bit limbs)
 template <class C>
-__global__ void __launch_bounds__(256) bases_to29_kernel(const Affine<C>* __restrict__ in, Affine<F29View<C>>* __restrict__ out, uint64_t n) {
+__device__ __forceinline__ void pack_base(Affine<C>& r, const Affine<C29<C>>& q) {
+    fe29_pack(r.x, q.x);
+    fe29_pack(r.y, q.y);
+}
+template <class C>
+__device__ __forceinline__ void pack_base(Affine<C>& r, const Affine<C29x2<C>>& q) {
+    fe29_pack(r.x.c0, q.x.c0);
+    fe29_pack(r.x.c1, q.x.c1);
+    fe29_pack(r.y.c0, q.y.c0);
+    fe29_pack(r.y.c1, q.y.c1);
+}
+// bases as uploaded (x R mod p)  ->  what the lazy-limb bucket kernels gather: x R' mod p (R' = 2^261 / 2^392), strict limbs below
+// 2p, packed back into 32-bit words (StoredBase above); (0, 0) stays (0, 0)
+template <class C>
+__global__ void __launch_bounds__(256) bases_to29_kernel(const Affine<C>* __restrict__ in, StoredAffine<F29View<C>>* __restrict__ out, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<C> p = in[i];
     Affine<F29View<C>> q;
     aff29_from_std(q, p);
-    out[i] = q;
+    Affine<C> r;
+    pack_base(r, q);
+    out[i] = r;
 }
 
 // out[i] = [k_i] G in affine form (k canonical).  Used to build seeded test / bench bases

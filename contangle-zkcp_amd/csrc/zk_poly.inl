@@ -152,15 +152,19 @@ int expr_eval_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const v
     const size_t pb = sizeof(ExprOp) * EXPR_MAX_OPS, cb = sizeof(void*) * EXPR_MAX_COLS, kb = sizeof(Fe<F>) * EXPR_MAX_CONSTS;
     ZK_TRY(ws_get(ss->poly_tot, pb + cb + kb + 64));
     unsigned char* base = (unsigned char*)ss->poly_tot.p;
-    HIP_TRY(hipMemcpyAsync(base, prog, sizeof(ExprOp) * n_ops, hipMemcpyHostToDevice, st));
+    // one aligned 64-bit word per op for the kernel: op | rot << 16 | arg << 32
+    std::vector<uint64_t> words(n_ops);
+    for (uint32_t k = 0; k < n_ops; k++)
+        words[k] = (uint64_t)prog[k].op | ((uint64_t)(uint16_t)prog[k].rot << 16) | ((uint64_t)prog[k].arg << 32);
+    HIP_TRY(hipMemcpyAsync(base, words.data(), sizeof(uint64_t) * n_ops, hipMemcpyHostToDevice, st));
     if (n_cols) HIP_TRY(hipMemcpyAsync(base + pb, cols, sizeof(void*) * n_cols, hipMemcpyHostToDevice, st));
     if (n_consts) HIP_TRY(hipMemcpyAsync(base + pb + cb, consts, sizeof(Fe<F>) * n_consts, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));   // the sources are the caller's host memory
     const uint64_t n = 1ull << log_n;
     uint64_t blocks = (n + EXPR_WG - 1) / EXPR_WG;
     if (blocks > 8192) blocks = 8192;
-    ZK_LAUNCH((expr_eval_kernel<F>), (unsigned)blocks, EXPR_WG, 0, st, (const ExprOp*)base, n_ops, (const Fe<F>* const*)(base + pb),
-              (const Fe<F>*)(base + pb + cb), log_n, rot_scale, out);
+    ZK_LAUNCH((expr_eval_kernel<F>), (unsigned)blocks, EXPR_WG, 0, st, (const uint64_t*)base, n_ops, (const Fe<F>* const*)(base + pb), n_cols,
+              (const Fe<F>*)(base + pb + cb), n_consts, log_n, rot_scale, out);
     HIP_TRY(hipGetLastError());
     return ZK_OK;
 }

@@ -243,57 +243,68 @@ struct ExprOp {
 constexpr uint32_t EXPR_MAX_OPS = 512, EXPR_MAX_COLS = 64, EXPR_MAX_CONSTS = 32, EXPR_STACK = 8, EXPR_WG = 128;
 
 // LDS: per-lane stack, limb-major (bank-conflict-free): stack[(slot * N + limb) * EXPR_WG + lane]
+// The program is read as one aligned 64-bit word per op (op | rot << 16 | arg << 32) and decoded with shifts: every lane
+// runs the same program, so the compiler turns these reads into scalar loads, and a scalar load of a field at a 2-byte
+// offset inside the struct is not something to rely on.  Operand indices are clamped against the table sizes as well:
+// the host validates the program, the kernel still never indexes past its tables.
 template <class F>
-__global__ void __launch_bounds__(EXPR_WG) expr_eval_kernel(const ExprOp* __restrict__ prog, uint32_t n_ops, const Fe<F>* const* __restrict__ cols,
-                                                            const Fe<F>* __restrict__ consts, uint32_t log_n, uint32_t rot_scale,
-                                                            Fe<F>* __restrict__ out) {
+__global__ void __launch_bounds__(EXPR_WG) expr_eval_kernel(const uint64_t* __restrict__ prog, uint32_t n_ops, const Fe<F>* const* __restrict__ cols,
+                                                            uint32_t n_cols, const Fe<F>* __restrict__ consts, uint32_t n_consts, uint32_t log_n,
+                                                            uint32_t rot_scale, Fe<F>* __restrict__ out) {
     __shared__ uint32_t stack[EXPR_STACK * F::N * EXPR_WG];
     const uint32_t lane = threadIdx.x;
     const uint64_t n = 1ull << log_n, mask = n - 1;
-    auto push = [&](uint32_t sp, const Fe<F>& x) {
-        ZK_UNROLL
-        for (int l = 0; l < F::N; l++) stack[(sp * F::N + l) * EXPR_WG + lane] = x.v[l];
-    };
-    auto peek = [&](uint32_t sp, Fe<F>& x) {
-        ZK_UNROLL
-        for (int l = 0; l < F::N; l++) x.v[l] = stack[(sp * F::N + l) * EXPR_WG + lane];
-    };
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + lane; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t sp = 0;
         for (uint32_t k = 0; k < n_ops; k++) {
-            const ExprOp o = prog[k];
+            const uint64_t w = prog[k];
+            const uint32_t op = (uint32_t)(w & 0xff), arg = (uint32_t)(w >> 32);
+            const int32_t rot = (int32_t)(int16_t)(uint16_t)(w >> 16);
             Fe<F> x, y;
-            if (o.op == 0) {
-                const uint64_t j = (i + (uint64_t)((int64_t)o.rot * (int64_t)rot_scale)) & mask;
-                x = cols[o.arg][j];
-                push(sp++, x);
-            } else if (o.op == 1) {
-                x = consts[o.arg];
-                push(sp++, x);
-            } else if (o.op == 5) {
-                peek(sp - 1, x);
-                fe_neg(x, x);
-                push(sp - 1, x);
-            } else if (o.op == 6) {
-                peek(sp - 1, x);
-                y = consts[o.arg];
-                fe_mul(x, x, y);
-                push(sp - 1, x);
+            if (op <= 1) {
+                if (sp >= EXPR_STACK) break;
+                if (op == 0) {
+                    const uint64_t j = (i + (uint64_t)((int64_t)rot * (int64_t)rot_scale)) & mask;
+                    x = cols[arg < n_cols ? arg : 0][j];
+                } else {
+                    x = consts[arg < n_consts ? arg : 0];
+                }
+                ZK_UNROLL
+                for (int l = 0; l < F::N; l++) stack[(sp * F::N + l) * EXPR_WG + lane] = x.v[l];
+                sp++;
+            } else if (op == 5 || op == 6) {
+                if (sp < 1) break;
+                ZK_UNROLL
+                for (int l = 0; l < F::N; l++) x.v[l] = stack[((sp - 1) * F::N + l) * EXPR_WG + lane];
+                if (op == 5) {
+                    fe_neg(x, x);
+                } else {
+                    y = consts[arg < n_consts ? arg : 0];
+                    fe_mul(x, x, y);
+                }
+                ZK_UNROLL
+                for (int l = 0; l < F::N; l++) stack[((sp - 1) * F::N + l) * EXPR_WG + lane] = x.v[l];
             } else {
-                peek(sp - 2, x);
-                peek(sp - 1, y);
-                if (o.op == 2)
+                if (sp < 2) break;
+                ZK_UNROLL
+                for (int l = 0; l < F::N; l++) {
+                    x.v[l] = stack[((sp - 2) * F::N + l) * EXPR_WG + lane];
+                    y.v[l] = stack[((sp - 1) * F::N + l) * EXPR_WG + lane];
+                }
+                if (op == 2)
                     fe_add(x, x, y);
-                else if (o.op == 3)
+                else if (op == 3)
                     fe_sub(x, x, y);
                 else
                     fe_mul(x, x, y);
                 sp--;
-                push(sp - 1, x);
+                ZK_UNROLL
+                for (int l = 0; l < F::N; l++) stack[((sp - 1) * F::N + l) * EXPR_WG + lane] = x.v[l];
             }
         }
         Fe<F> r;
-        peek(0, r);
+        ZK_UNROLL
+        for (int l = 0; l < F::N; l++) r.v[l] = stack[l * EXPR_WG + lane];
         out[i] = r;
     }
 }
