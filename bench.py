@@ -83,6 +83,7 @@ def setup():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="NTTs and MSMs on one stream, MSMs one at a time (no overlap)")
     ap.add_argument("--workload", default="halo2", choices=["halo2", "column", "groth16"])
+    ap.add_argument("--ntt-limbs", type=int, default=0, choices=[0, 32], help="0: lazy 29-bit limbs inside the NTT tiles (default); 32: saturated words (A/B)")
     args = ap.parse_args()
 
     import numpy as np
@@ -117,6 +118,8 @@ def setup():
     e.zk, e.zkdist, e.synth = zk, zkdist, synth
     zk.load()
     zk.init(local_rank)
+    if args.ntt_limbs:
+        zk.ntt_configure(limb_bits=args.ntt_limbs)
     e.st = torch.cuda.current_stream().cuda_stream
     return e
 

@@ -151,9 +151,10 @@ def device_count():
     return load().zk_device_count()
 
 
-def ntt_configure(max_log_radix=0, log_tile=None, block=0):
-    """process-wide NTT plan knobs (tuning harness / tests); no arguments restores the defaults"""
-    o = NttOpts(max_log_radix, 0 if log_tile is None else log_tile + 1, block, 0)
+def ntt_configure(max_log_radix=0, log_tile=None, block=0, limb_bits=0):
+    """process-wide NTT plan knobs (tuning harness / tests); no arguments restores the defaults.
+    limb_bits: 0 = lazy 29-bit limbs inside the tiles (default), 32 = saturated words"""
+    o = NttOpts(max_log_radix, 0 if log_tile is None else log_tile + 1, block, limb_bits)
     _check(load().zk_ntt_configure(ctypes.byref(o)), "zk_ntt_configure")
 
 

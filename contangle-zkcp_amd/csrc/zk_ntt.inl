@@ -3,6 +3,7 @@
 #include "zk_internal.h"
 #include "zk_ntt_decl.h"
 #include "zk_ntt_kernels.h"
+#include "zk_ntt29_kernels.h"
 #include "zk_r1cs_kernels.h"
 namespace zk {
 // ------------------------------------------------------------------ NTT
@@ -48,10 +49,10 @@ inline NttPlan ntt_plan(uint32_t logn) {
 }
 
 template <class F>
-int tw_table(DeviceCtx& dc, const Fe<F>& omega, uint32_t logn, int field, hipStream_t st, const Fe<F>** out) {
+int tw_table(DeviceCtx& dc, const Fe<F>& omega, uint32_t logn, int field, hipStream_t st, const Fe<F>** out, bool r29 = false) {
     TwKey key;
     memset(&key, 0, sizeof key);
-    key.field = field;
+    key.field = field | (r29 ? 0x200 : 0);   // the lazy-limb pass reads omega^i R' mod p, the saturated one omega^i R mod p
     key.logn = logn;
     memcpy(key.omega, omega.v, sizeof(uint32_t) * F::N);
     auto it = dc.tw.find(key);
@@ -86,6 +87,7 @@ int tw_table(DeviceCtx& dc, const Fe<F>& omega, uint32_t logn, int field, hipStr
     const unsigned blk = 256;
     ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((count + blk - 1) / blk), blk, 0, st, (Fe<F>*)dev, (const Fe<F>*)dc.pow_tbl.p,
               count, nbits);
+    if (r29) ZK_LAUNCH((table_to_r29_kernel<F>), (unsigned)((count + blk - 1) / blk), blk, 0, st, (Fe<F>*)dev, count);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // pow_tbl is reused by the next table build
     TwEntry e{dev, sizeof(Fe<F>) * count, ++dc.tw_stamp};
@@ -97,10 +99,10 @@ int tw_table(DeviceCtx& dc, const Fe<F>& omega, uint32_t logn, int field, hipStr
 
 // device tables lo[j] = g^j (j < min(n,1024)), hi[j] = g^(1024 j) (j < max(1, n/1024)) for on-the-fly coset powers; cached
 template <class F>
-int pow_tables(DeviceCtx& dc, const Fe<F>& gshift, uint32_t logn, int field, hipStream_t st, PowTables<F>* out) {
+int pow_tables(DeviceCtx& dc, const Fe<F>& gshift, uint32_t logn, int field, hipStream_t st, PowTables<F>* out, bool r29 = false) {
     TwKey key;
     memset(&key, 0, sizeof key);
-    key.field = field | 0x100;   // separate key space from the twiddle tables
+    key.field = field | (r29 ? 0x300 : 0x100);   // separate key spaces from the twiddle tables; 0x300: entries in R' form
     key.logn = logn;
     memcpy(key.omega, gshift.v, sizeof(uint32_t) * F::N);
     auto it = dc.tw.find(key);
@@ -133,6 +135,7 @@ int pow_tables(DeviceCtx& dc, const Fe<F>& gshift, uint32_t logn, int field, hip
         HIP_TRY(hipMemcpyAsync(d_lad, lad.data(), sizeof(Fe<F>) * 64, hipMemcpyHostToDevice, st));
         ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nlo + 255) / 256), 256, 0, st, (Fe<F>*)dev, (const Fe<F>*)d_lad, nlo, 10);
         ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nhi + 255) / 256), 256, 0, st, (Fe<F>*)dev + nlo, (const Fe<F>*)(d_lad + 32), nhi, 22);
+        if (r29) ZK_LAUNCH((table_to_r29_kernel<F>), (unsigned)((nlo + nhi + 255) / 256), 256, 0, st, (Fe<F>*)dev, nlo + nhi);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));   // `lad` is a host temporary
         TwEntry e{dev, bytes, ++dc.tw_stamp};
@@ -152,11 +155,13 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
             const Fe<F>* g_post, uint32_t in_log) {
     if (logn > (uint32_t)F::TWO_ADICITY || logn > 30) return ZK_ERR_INVALID_ARG;   // before anything is sized from logn
     if (logn == 0) return ZK_OK;  // size-1 transform is the identity, n^-1 = 1 and g^0 = 1
+    // lazy 29-bit limbs inside the tiles (zk_ntt29_kernels.h) unless zk_ntt_opts asks for the saturated words
+    const bool lazy = g.ntt_opts.reserved != 32;
     PowTables<F> tpre{nullptr, nullptr}, tpost{nullptr, nullptr};
-    if (g_pre) ZK_TRY(pow_tables<F>(dc, *g_pre, logn, field, st, &tpre));
-    if (g_post) ZK_TRY(pow_tables<F>(dc, *g_post, logn, field, st, &tpost));
+    if (g_pre) ZK_TRY(pow_tables<F>(dc, *g_pre, logn, field, st, &tpre, lazy));
+    if (g_post) ZK_TRY(pow_tables<F>(dc, *g_post, logn, field, st, &tpost, lazy));
     const Fe<F>* tw = nullptr;
-    ZK_TRY(tw_table<F>(dc, omega, logn, field, st, &tw));
+    ZK_TRY(tw_table<F>(dc, omega, logn, field, st, &tw, lazy));
     Fe<F> scale;
     fe_one(scale);
     if (scale_flag) {
@@ -165,6 +170,10 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
         nn.v[logn / 32] = 1u << (logn % 32);
         fe_to_mont(nn, nn);
         fe_inv(scale, nn);
+    }
+    if (lazy) {   // the last pass always multiplies by `scale`: n^-1 (or 1) in R' form
+        constexpr int SH = F29<F>::W * F29<F>::L - 32 * F::N;
+        for (int k = 0; k < SH; k++) fe_dbl(scale, scale);
     }
     NttPlan plan = ntt_plan(logn);
     Fe<F>* tmp = nullptr;
@@ -212,10 +221,15 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
             if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) max_blk = (unsigned)v;
         }
         unsigned blk = rt / 2 < 64 ? 64 : (rt / 2 > max_blk ? max_blk : rt / 2);
-        const size_t shmem = (size_t)rt * sizeof(Fe<F>);
-        if (shmem > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        const size_t shmem = (size_t)rt * (lazy ? sizeof(Fe29<F>) : sizeof(Fe<F>));
+        if (shmem > 48 * 1024) {
+            if (lazy)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass29_kernel<F>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            else
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (g.ntt_profile) {   // bracket the launch with events on its own stream (zk_ntt_profile_read sums them)
             while (dc.ntt_ev_pool.size() < dc.ntt_ev_used + 2) {
@@ -227,7 +241,10 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
             e1 = dc.ntt_ev_pool[dc.ntt_ev_used++];
             HIP_TRY(hipEventRecord(e0, st));
         }
-        ZK_LAUNCH((ntt_pass_kernel<F>), (unsigned)tiles, blk, shmem, st, src, dst, tw, A, scale, tpre, tpost);
+        if (lazy)
+            ZK_LAUNCH((ntt_pass29_kernel<F>), (unsigned)tiles, blk, shmem, st, src, dst, tw, A, scale, tpre, tpost);
+        else
+            ZK_LAUNCH((ntt_pass_kernel<F>), (unsigned)tiles, blk, shmem, st, src, dst, tw, A, scale, tpre, tpost);
         if (e1) HIP_TRY(hipEventRecord(e1, st));
         HIP_TRY(hipGetLastError());
         log_m += plan.rd[p];

@@ -168,3 +168,13 @@ def test_halo2_ipa(zk):
 
 def test_halo2_expression(zk):
     ps.check_expression(zk, "PallasFp", 4)
+
+
+def test_ntt_saturated_limbs_path(zk, ntt_plan):
+    """the 32-bit-word butterflies stay reachable through zk_ntt_opts (A/B measurements) and agree with the oracle too"""
+    ntt_plan(limb_bits=32)
+    ps.check_ntt_vs_oracle(zk, "PallasFp", 11)
+    ps.check_ntt_fused_coset(zk, "Bls381Fr", 6)
+    ps.check_ntt_extend(zk, "Bn254Fr", 5, 8)
+    ntt_plan(limb_bits=32, max_log_radix=3)
+    ps.check_ntt_vs_oracle(zk, "PallasFq", 8)

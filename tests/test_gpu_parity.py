@@ -525,3 +525,36 @@ def test_halo2_products_2p20(zk):
     torch.cuda.synchronize()
     one = orc.to_mont(name, orc.ints_to_array([1], 4))[0]
     assert (inv.cpu().numpy().view(np.uint64) == one).all()
+
+
+def test_ntt_saturated_limbs_path(zk):
+    """zk_ntt_opts limb_bits = 32: the saturated-word butterflies (the default is the lazy 29-bit form) against the oracle"""
+    zk.ntt_configure(limb_bits=32)
+    try:
+        ps.check_ntt_vs_oracle(zk, "PallasFp", 20, threads=16)
+        ps.check_ntt_vs_oracle(zk, "Bn254Fr", 13)
+        ps.check_ntt_fused_coset(zk, "Bls381Fr", 16, threads=16)
+        ps.check_ntt_extend(zk, "PallasFq", 10, 13)
+        ps.check_witness_map(zk, "Bls381Fr", 12)
+    finally:
+        zk.ntt_configure()
+
+
+def test_ntt_lazy_limbs_extremes(zk):
+    """the lazy-limb tiles at the edge of their bounds: all-(p - 1) inputs (largest values on every sum path), all zeros,
+    alternating 0 / p - 1, for the deepest tile (2^10 points per pass) of every field"""
+    from oracle import pyref
+    for name in ps.NTT_FIELDS:
+        p = pyref.FIELDS[name][0]
+        for logn in (10, 20):
+            n = 1 << logn
+            w = orc.root_of_unity(name, logn)
+            top = orc.int_to_limbs(p - 1, 4)          # as stored words: the largest canonical value
+            for pattern in ("max", "alt", "zero"):
+                a = np.zeros((n, 4), dtype=np.uint64)
+                if pattern == "max":
+                    a[:] = top
+                elif pattern == "alt":
+                    a[::2] = top
+                got = zk.halo2.best_fft(name, a, w, logn)
+                assert (got == orc.halo2_best_fft(name, a, w, logn, threads=16)).all(), (name, logn, pattern)

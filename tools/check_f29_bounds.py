@@ -253,7 +253,35 @@ def check_shape_ext2(w, l, log2p_max, log2p_min):
         assert mul(norm(c), V(STRICT, 1)).vb < 2
 
 
+def check_ntt_tile(w, l, log2p_max, log2p_min, max_log_r=10):
+    """The lazy-limb NTT tile (zk_ntt29_kernels.h): decimation-in-time butterflies  t = w tw ; o0 = u + t ; o1 = u - t + 4p
+    with one parallel carry step after every third stage.  Every element of the tile is bounded by the same (LB, VB) state;
+    elements enter below 2p with strict limbs and must leave, after one more product, below 2p again (they are stored in
+    256 bits)."""
+    configure(w, l, log2p_max, log2p_min)
+    tw = V(STRICT, 1.0, "twiddle")                     # canonical, < p
+    worst = 0.0
+    for log_r in range(1, max_log_r + 1):
+        st = V(STRICT, 2.0, "loaded")                  # < 2p: the caller's canonical value or what an earlier pass stored
+        for lg in range(log_r):
+            t = mul(st, tw, "w*tw") if lg > 0 else st  # stage 0 has no twiddle: the operand is a fresh load
+            assert t.lb <= STRICT and t.vb <= 2.0, t
+            o0 = add(st, t, "u+t")
+            o1 = sub(st, [t], "4K1", "u-t+4p")
+            st = V(max(o0.lb, o1.lb), max(o0.vb, o1.vb), "stage %d" % lg)
+            if lg % 3 == 2:
+                st = norm(st, "carry")
+        out = mul(st, tw, "store")                     # inter-pass twiddle / scale factor / R'
+        assert out.vb <= 2.0, out
+        worst = max(worst, st.vb)
+    assert worst * 2.0 ** log2p_max < 2.0 ** (W * (L - 1) + 32), "top limb overflow"
+    return worst
+
+
 def main():
+    for shape in ((29, 9, 255.0, 253.5),):
+        vb = check_ntt_tile(*shape)
+        print("NTT tile %d x %d: bounds hold for tiles up to 2^10 points (largest value bound %.0f p)" % (shape[1], shape[0], vb))
     check_shape(29, 9, 254.001, 253.5)     # Pasta Fp / Fq (p = 2^254 (1 + 2^-128)), BN254 Fq (2^253.6)
     check_shape(28, 14, 380.8, 380.6)      # BLS12-381 Fq (2^380.7)
     check_shape_ext2(29, 9, 254.001, 253.5)    # BN254 G2
