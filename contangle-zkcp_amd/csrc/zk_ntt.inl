@@ -83,14 +83,20 @@ int tw_table(DeviceCtx& dc, const Fe<F>& omega, uint32_t logn, int field, hipStr
     ZK_TRY(ws_get(dc.pow_tbl, sizeof(Fe<F>) * 64));
     HIP_TRY(hipMemcpyAsync(dc.pow_tbl.p, tbl.data(), sizeof(Fe<F>) * tbl.size(), hipMemcpyHostToDevice, st));
     void* dev = nullptr;
-    HIP_TRY(hipMalloc(&dev, sizeof(Fe<F>) * count));
+    const uint32_t n_inner = logn > 0 ? 1u << ((logn < (uint32_t)NTT_INNER_LOG ? logn : (uint32_t)NTT_INNER_LOG) - 1) : 1u;
+    HIP_TRY(hipMalloc(&dev, sizeof(Fe<F>) * count + (r29 ? sizeof(InnerTw) * n_inner : 0)));
     const unsigned blk = 256;
     ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((count + blk - 1) / blk), blk, 0, st, (Fe<F>*)dev, (const Fe<F>*)dc.pow_tbl.p,
               count, nbits);
-    if (r29) ZK_LAUNCH((table_to_r29_kernel<F>), (unsigned)((count + blk - 1) / blk), blk, 0, st, (Fe<F>*)dev, count);
+    if (r29) {
+        ZK_LAUNCH((table_to_r29_kernel<F>), (unsigned)((count + blk - 1) / blk), blk, 0, st, (Fe<F>*)dev, count);
+        // the compact unpacked table of the in-tile twiddles, behind the big one
+        const int shift = logn > (uint32_t)NTT_INNER_LOG ? (int)logn - NTT_INNER_LOG : 0;
+        ZK_LAUNCH((inner_table_kernel<F>), (n_inner + blk - 1) / blk, blk, 0, st, (const Fe<F>*)dev, (InnerTw*)((Fe<F>*)dev + count), n_inner, shift);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // pow_tbl is reused by the next table build
-    TwEntry e{dev, sizeof(Fe<F>) * count, ++dc.tw_stamp};
+    TwEntry e{dev, sizeof(Fe<F>) * count + (r29 ? sizeof(InnerTw) * n_inner : 0), ++dc.tw_stamp};
     dc.tw[key] = e;
     dc.tw_bytes += e.bytes;
     *out = (const Fe<F>*)dev;
@@ -242,7 +248,8 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
             HIP_TRY(hipEventRecord(e0, st));
         }
         if (lazy)
-            ZK_LAUNCH((ntt_pass29_kernel<F>), (unsigned)tiles, blk, shmem, st, src, dst, tw, A, scale, tpre, tpost);
+            ZK_LAUNCH((ntt_pass29_kernel<F>), (unsigned)tiles, blk, shmem, st, src, dst, tw, (const InnerTw*)(tw + (logn > 0 ? (1ull << (logn - 1)) : 1)),
+                      A, scale, tpre, tpost);
         else
             ZK_LAUNCH((ntt_pass_kernel<F>), (unsigned)tiles, blk, shmem, st, src, dst, tw, A, scale, tpre, tpost);
         if (e1) HIP_TRY(hipEventRecord(e1, st));

@@ -44,9 +44,30 @@ __global__ void __launch_bounds__(256) table_to_r29_kernel(Fe<F>* __restrict__ t
     tbl[i] = x;
 }
 
+// The butterflies inside a tile only ever need the 2^(IL-1) powers omega^(m n / 2^IL), IL = min(log n, 10) (stage lg uses
+// m = k << (IL - 1 - lg)): kept as a compact table of UNPACKED limbs (12 words = 48 B per entry, 24 KB: cache-resident)
+// behind the n/2-entry table, which only the inter-pass twiddles read.  Saves the 18 shift / mask pairs of an unpack in
+// every butterfly and turns a 128 MB-strided gather into reads of one small table.
+constexpr int NTT_INNER_LOG = 10;
+struct alignas(16) InnerTw {
+    uint32_t v[12];
+};
+template <class F>
+__global__ void __launch_bounds__(256) inner_table_kernel(const Fe<F>* __restrict__ tw, InnerTw* __restrict__ out, uint32_t count, int shift) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= count) return;
+    const Fe<F> raw = tw[(uint64_t)m << shift];
+    Fe29<F> t;
+    fe29_unpack(t, raw);
+    InnerTw o;
+    for (int l = 0; l < 12; l++) o.v[l] = l < F29<F>::L ? t.v[l] : 0u;
+    out[m] = o;
+}
+
 template <class F>
 __global__ void __launch_bounds__(1024) ntt_pass29_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out, const Fe<F>* __restrict__ tw,
-                                                          NttPass A, Fe<F> scale, PowTables<F> pre, PowTables<F> post) {
+                                                          const InnerTw* __restrict__ inner, NttPass A, Fe<F> scale, PowTables<F> pre,
+                                                          PowTables<F> post) {
     ZK_DYN_SHARED(uint32_t, lds);
     using K = F29<F>;
     constexpr int NL = K::L;
@@ -87,6 +108,13 @@ __global__ void __launch_bounds__(1024) ntt_pass29_kernel(const Fe<F>* __restric
     }
     auto pos = [&](uint32_t j, uint32_t t) -> uint32_t { return A.last ? (t << A.log_r) + j : (j << A.log_t) + t; };
 
+    // Zero-extended input (halo2 coeff_to_extended): only radix-axis indices j < J = 2^(in_log - log_s) are non-zero.  In
+    // bit-reversed placement they land on the slots that are multiples of 2^z (z = log_r - log2 J), and the first z
+    // stages pair each of them with zeros only: after those stages every slot of an aligned group of 2^z holds the
+    // group's one value (u + 0 and u - 0 + 4p are the same residue).  So the value is written to its whole group on load
+    // and the butterflies start at stage z: 3 of the 23 stages of a 2^20 -> 2^23 extension never run.
+    int z = 0;
+    if (A.in_log > 0 && A.log_m == 0 && A.in_log >= log_s && A.in_log - log_s < A.log_r) z = A.log_r - (A.in_log - log_s);
     // ---- load the tile: radix-axis index j goes to slot bitrev(j) (decimation in time)
     for (uint32_t e = tid; e < RT; e += nth) {
         uint32_t j, t;
@@ -99,22 +127,27 @@ __global__ void __launch_bounds__(1024) ntt_pass29_kernel(const Fe<F>* __restric
         }
         const uint64_t gi = base + j * stride_j + t * stride_t;
         Fe29<F> x;
-        if (A.in_log > 0 && (gi >> A.in_log) != 0) {
+        const bool padded = A.in_log > 0 && (gi >> A.in_log) != 0;
+        if (padded) {
+            if (z > 0) continue;                      // its slot is filled by the group's one non-zero element
             fe29_zero(x);
         } else {
             const Fe<F> raw = in[gi];
             fe29_unpack(x, raw);                      // strict limbs, V < 2p
             if (A.pre) mul_pow29(x, pre, gi);
         }
-        const uint32_t p = pos(bitrev32(j, A.log_r), t);
-        ZK_UNROLL
-        for (int l = 0; l < NL; l++) lds[l * RT + p] = x.v[l];
+        const uint32_t slot = bitrev32(j, A.log_r);
+        for (uint32_t c = 0; c < (1u << z); c++) {
+            const uint32_t p = pos(slot + c, t);
+            ZK_UNROLL
+            for (int l = 0; l < NL; l++) lds[l * RT + p] = x.v[l];
+        }
     }
     __syncthreads();
 
     // ---- radix-2 DIT butterflies over the R axis
     const uint32_t nbf = RT >> 1;
-    for (int lg = 0; lg < A.log_r; lg++) {
+    for (int lg = z; lg < A.log_r; lg++) {
         const uint32_t g = 1u << lg;
         const bool carry = (lg % 3) == 2;
         for (uint32_t b = tid; b < nbf; b += nth) {
@@ -135,10 +168,11 @@ __global__ void __launch_bounds__(1024) ntt_pass29_kernel(const Fe<F>* __restric
                 w.v[l] = lds[l * RT + p1];
             }
             if (lg > 0) {
-                const uint64_t e = (uint64_t)(q & (g - 1)) << (A.logn - 1 - lg);
-                const Fe<F> traw = tw[e];
+                const int il = A.logn < NTT_INNER_LOG ? A.logn : NTT_INNER_LOG;
+                const InnerTw traw = inner[(q & (g - 1)) << (il - 1 - lg)];
                 Fe29<F> tv;
-                fe29_unpack(tv, traw);
+                ZK_UNROLL
+                for (int l = 0; l < NL; l++) tv.v[l] = traw.v[l];
                 fe29_mul(w, w, tv);                   // strict, < 2p
             }
             fe29_add(s, u, w);
