@@ -2,15 +2,13 @@
 """Headline bench: the GPU work-list of ONE proof of the synthetic 2^20-row halo2 PoE circuit (BASELINE.json configs[2],
 the configuration `metric` is quoted on), inputs resident in HBM, through the C ABI (libzkcp_amd.so).
 
-  step (default, --workload halo2): column layout of the reference's ElGamalGadget (13 advice columns,
-      circuits-halo2/src/encryption.rs:83-161; SURVEY 8a a11 / 8d "Config 3"):
-        13 x commit(advice column)   = best_multiexp over Params::g_lagrange (Vesta, 2^k Montgomery scalars) -- one batched
-                                       call, the columns share the bases
-        13 x lagrange_to_coeff       = iNTT 2^k
-        13 x coeff_to_extended       = zero-extend to 2^(k+3), zeta-coset shift, NTT 2^(k+3)
-         1 x extended_to_coeff       = iNTT 2^(k+3) + coset un-shift (the quotient polynomial)
-      The NTT chain of a column does not depend on the column's commitment, so it runs on a second HIP stream beside
-      the MSMs.  IPA opening, permutation / lookup products and the transcript are not part of this line.
+  step (default, --workload halo2): the device work-list of one halo2_proofs 0.2 create_proof over the column layout of the
+      reference's ElGamalGadget (13 advice, 8 fixed, a lookup, equality over 16 columns, degree-9 gates;
+      circuits-halo2/src/encryption.rs:83-161; SURVEY 8a a11 / 8d "Config 3"), in upstream's order -- see bench_halo2():
+      advice commits + NTT chains, lookup and permutation grand products with their commits and chains, the quotient
+      (expression evaluation on the extended coset, division by the vanishing polynomial, extended_to_coeff, 8 h-piece
+      commits) and the k-round inner-product argument.  NTT chains run on a second HIP stream beside the batched MSMs.
+      RNG, transcript and the lookup's sort stay on the CPU; evaluations at x / the multiopen combination are not in the list.
   metric    = constraints/sec = rows / wall-clock of the timed region (whole job)
   --workload column : BASELINE configs[1], one 2^20 MSM + one 2^20 NTT per step (the microbench; prints msm_mops)
   --workload groth16: the GPU work of one Groth16 proof at domain 2^logn (SURVEY 8d "Config 4")
@@ -77,7 +75,8 @@ def setup():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logn", type=int, default=20)
-    ap.add_argument("--curve", default="Vesta", choices=["Vesta", "Pallas", "Bn254G1", "Bls381G1"])
+    ap.add_argument("--curve", default="Vesta", choices=["Vesta", "Pallas", "Bn254G1", "Bls381G1", "Bn254G2", "Bls381G2"],
+                    help="MSM curve of the column workload (G2: Groth16's b_g2_query shape); pairing family of the groth16 workload")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--realistic", action="store_true", help="0/1-heavy witness mix (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -208,7 +207,9 @@ def emit(e, line, roofs):
             # second view: the 32x32->64 MADs a mixed add strictly needs vs the measured v_mad_u64_u32 peak
             # (tools/microbench: 33.7 T/s).  MADs per Montgomery product in the lazy limb form: L^2 for a*b plus L per
             # non-zero modulus limb for m*p.
-            mads = {"Vesta": 135, "Pallas": 135, "Bn254G1": 162, "Bls381G1": 392}.get(line["config"].get("msm_curve", ""), None)
+            # an Fq2 product on lazy limbs is two double products sharing one reduction each (zk_field29.h): 2 x (2 L^2 + reduction)
+            mads = {"Vesta": 135, "Pallas": 135, "Bn254G1": 162, "Bls381G1": 392, "Bn254G2": 4 * 81 + 2 * 81, "Bls381G2": 4 * 196 + 2 * 196}.get(
+                line["config"].get("msm_curve", ""), None)
             if mads:
                 adds = line["config"]["msm_points"] * line["config"]["msm_windows_done"]
                 a = adds * 10 * mads / (acc["avg_launch_us"] * 1e-6) / 1e12
@@ -233,68 +234,204 @@ def base_line(e, value, elapsed, workload, cfg):
 
 
 # ---------------------------------------------------------------------------------------------------- halo2 (default)
+N_FIXED, N_PERM_COLS, PERM_CHUNK, N_H_PIECES = 8, 16, 7, 8     # reference circuit: 8 fixed columns; equality over 16 columns; degree 9
+
+
+def quotient_program(n_adv, n_fix):
+    """A gate set in the style of the reference's circuit (circuits-halo2/src/encryption.rs:83-161: ECC-style multiplication
+    gates, a Pow5 S-box with a rotation, boolean / range checks behind fixed selectors, the lookup and permutation argument
+    constraints), folded with y: columns [0, n_adv) advice, [n_adv, n_adv + n_fix) fixed, then A', S', Z_lookup, Z_perm x3.
+    consts: [y, 5, 1, beta, gamma]"""
+    A = lambda i, r=0: ("col", i % n_adv, r)
+    Fx = lambda i, r=0: ("col", n_adv + i % n_fix, r)
+    X = n_adv + n_fix
+    ap, sp, zl = ("col", X, 0), ("col", X + 1, 0), ("col", X + 2, 0)
+    zp = [("col", X + 3 + c, 0) for c in range(3)]
+    prog = []
+    # every term after the first is folded in as  acc = acc * y + term
+    # multiplication gates  q (a b - c), eight of them
+    first = True
+    for g in range(8):
+        term = [Fx(g), A(g), A(g + 1), ("mul",), A(g + 2), ("sub",), ("mul",)]
+        prog.extend(term if first else [("scale", 0)] + term + [("add",)])
+        first = False
+    # Pow5 with a rotation  q (a^5 + 5 - b(omega X)), three of them
+    for g in range(3):
+        a = A(3 * g + 1)
+        prog.extend([("scale", 0), Fx(g + 3), a, a, ("mul",), a, ("mul",), a, ("mul",), a, ("mul",), ("const", 1), ("add",),
+                     ("col", (3 * g + 2) % n_adv, 1), ("sub",), ("mul",), ("add",)])
+    # boolean checks  q a (a - 1), four of them
+    for g in range(4):
+        a = A(g + 9)
+        prog.extend([("scale", 0), Fx(g + 4), a, a, ("const", 2), ("sub",), ("mul",), ("mul",), ("add",)])
+    # lookup: Z(omega X)(A' + beta)(S' + gamma) - Z(X)(A + beta)(S + gamma), and (A' - S')(A' - A'(omega^-1 X))
+    prog.extend([("scale", 0), ("col", X + 2, 1), ap, ("const", 3), ("add",), ("mul",), sp, ("const", 4), ("add",), ("mul",),
+                 zl, A(0), ("const", 3), ("add",), ("mul",), Fx(7), ("const", 4), ("add",), ("mul",), ("sub",), ("add",)])
+    prog.extend([("scale", 0), ap, sp, ("sub",), ap, ("col", X, -1), ("sub",), ("mul",), ("add",)])
+    # permutation, per chunk: Z(omega X) prod (v + beta s + gamma) - Z(X) prod (v + delta-term + gamma), two columns of each chunk written out
+    for c in range(3):
+        v0, v1 = A(2 * c), A(2 * c + 1)
+        prog.extend([("scale", 0), ("col", X + 3 + c, 1), v0, Fx(c), ("scale", 3), ("add",), ("const", 4), ("add",), ("mul",),
+                     v1, Fx(c + 1), ("scale", 3), ("add",), ("const", 4), ("add",), ("mul",),
+                     zp[c], v0, ("const", 4), ("add",), ("mul",), v1, ("const", 3), ("add",), ("mul",), ("sub",), ("add",)])
+    return prog
+
+
 def bench_halo2(e):
+    """The device work-list of one halo2_proofs 0.2 create_proof over a 2^k-row circuit with the reference circuit's column
+    layout, in upstream's order; RNG (blinding rows / scalars), the transcript and the sort of the lookup's permuted columns
+    stay on the CPU and are represented by pre-made inputs / fixed challenges:
+      1 advice        13 x commit (batched MSM, Lagrange basis)   +  13 x (lagrange_to_coeff ; coeff_to_extended)
+      2 lookup        commit A', S' ; product Z_L (grand product) ; commit Z_L ; 3 x (l2c ; c2e)
+      3 permutation   3 chunks of <= 7 columns: product Z_P (each chunk continues the previous) ; 3 commits ; 3 x (l2c ; c2e)
+      4 quotient      commit the random polynomial ; gate / lookup / permutation expressions on the extended coset (one stack
+                      program, 268 ops of which 81 products, 27 columns) ; divide by the vanishing polynomial ; extended_to_coeff ; commit the 8 pieces of h
+      5 opening       the inner-product argument on the combined polynomial: k rounds of 2 MSMs + 2 inner products + 3 folds
+    (evaluations at x and the multiopen combination -- inner products / axpys over vectors already resident -- are not in the list)"""
     a, zk, torch, np = e.args, e.zk, e.torch, e.np
     curve = a.curve if a.curve in ("Vesta", "Pallas") else "Vesta"
     sfield = e.synth.CURVE_SCALAR_FIELD[curve]
     k, ext = a.logn, a.logn + 3
-    n = 1 << k
-    bases, d_pts = make_bases(e, curve, n, 0x5EED)
+    n, ne = 1 << k, 1 << (a.logn + 3)
+    g_lagrange, d_pts = make_bases(e, curve, n, 0x5EED)
+    g_coeff, d_pts_c = make_bases(e, curve, n, 0x5EEE)          # Params::g (coefficient basis): h pieces, random poly, IPA
     dom = zk.halo2.EvaluationDomain(sfield, 9, k)      # degree-9 gates -> extended_k = k + 3 (Orchard-style, SURVEY a10)
     assert dom.extended_k == ext
-    # 13 advice columns in Lagrange form (Montgomery residues, as halo2 holds them)
-    cols_host = np.stack([e.synth.rand_field(sfield, n, 0xC0DE + c) for c in range(NCOL)])
-    d_cols = to_dev(e, cols_host)                                   # [13, n, 4]
-    mine = [c for c in range(NCOL) if c % e.world == e.rank]        # NTT chains this rank owns
-    d_ext = [torch.empty((1 << ext, 4), dtype=torch.int64, device="cuda") for _ in mine]
-    d_quot = torch.empty((1 << ext, 4), dtype=torch.int64, device="cuda")
-    d_quot.copy_(to_dev(e, e.synth.rand_field(sfield, 1 << ext, 0xF00D)))
+    rf = lambda seed, m=n: e.synth.rand_field(sfield, m, seed)
+    cols_host = np.stack([rf(0xC0DE + c) for c in range(NCOL)])
+    d_cols = to_dev(e, cols_host)                                   # [13, n, 4] advice, Lagrange form
+    d_fixed_ext = [to_dev(e, rf(0xF1 + c, ne)) for c in range(N_FIXED)]          # fixed columns on the extended coset: key material
+    d_sigma = [to_dev(e, rf(0x51 + c)) for c in range(N_PERM_COLS)]              # permutation polynomials (Lagrange): key material
+    d_lookup = to_dev(e, np.stack([rf(0xA0), rf(0xA1), rf(0xA2), rf(0xA3)]))     # A, S and the permuted A', S' (the sort is upstream's CPU step)
+    d_rand = to_dev(e, rf(0xBB))                                                  # the vanishing argument's random polynomial
+    beta, gamma, delta, y = (rf(0xC1, 1)[0], rf(0xC2, 1)[0], rf(0xC3, 1)[0], rf(0xC4, 1)[0])
+    us = [rf(0xD0 + j, 1)[0] for j in range(k)]                                   # IPA challenges
+    consts = np.stack([y, zk.halo2._mont_limbs(5, dom._p), zk.halo2._mont_limbs(1, dom._p), beta, gamma])
+    # every chain (a Lagrange column -> coefficients -> extended coset) is owned by one rank; MSMs are sharded over all
+    # NTTs stay single-GPU (north_star): with N > 1 ranks every rank runs every chain and the quotient (replicated), the
+    # MSMs are what is sharded
+    chains = list(range(NCOL + 3 + 3))                              # advice 0..12, lookup A' S' Z_L, permutation Z_P x3
+    mine = chains
+    d_ext = {c: torch.empty((ne, 4), dtype=torch.int64, device="cuda") for c in chains}      # (all resident: the quotient reads all of them)
+    d_zl = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    d_zp = [torch.empty((n, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
+    d_h = torch.empty((ne, 4), dtype=torch.int64, device="cuda")
+    d_ipa = [torch.empty((n, 4), dtype=torch.int64, device="cuda") for _ in range(2)]
+    d_g = torch.empty_like(d_pts_c)
+    prog = quotient_program(NCOL, N_FIXED)
     main = torch.cuda.current_stream()
     side = main if a.serial else torch.cuda.Stream()
     result = {}
+    phase_ms = {"advice": 0.0, "lookup": 0.0, "permutation": 0.0, "quotient": 0.0, "opening": 0.0}
+
+    def chain(c, src, stream):
+        """Lagrange column -> coefficients -> extended coset (only on the rank that owns chain c)"""
+        if c in mine:
+            d_ext[c][:n].copy_(src, non_blocking=True)
+            dom.lagrange_to_coeff(d_ext[c][:n], stream=stream)
+            dom.coeff_to_extended(d_ext[c], stream=stream)
+
+    def commit_batch(bases, cols):
+        if a.serial:
+            return [e.zkdist.msm_sharded(bases, cols[c], montgomery=True, window_bits=a.window_bits, stream=e.st) for c in range(cols.shape[0])]
+        return e.zkdist.msm_batch_sharded(bases, cols, montgomery=True, window_bits=a.window_bits, stream=e.st)
 
     def step(i, timed_):
+        t0 = time.perf_counter()
+        # ---- 1 advice: NTT chains on the side stream beside the batched commitments
         side.wait_stream(main)
-        # NTT chains on the side stream ...
         with torch.cuda.stream(side):
-            for j, c in enumerate(mine):
-                d_ext[j][:n].copy_(d_cols[c], non_blocking=True)
-                dom.lagrange_to_coeff(d_ext[j][:n], stream=side.cuda_stream)
-                dom.coeff_to_extended(d_ext[j], stream=side.cuda_stream)
-            if e.rank == 0:
-                dom.extended_to_coeff(d_quot, stream=side.cuda_stream)
-        # ... beside the 13 commitments (one batched call: same bases, MSMs alternate between two library streams)
-        if a.serial:
-            outs = [e.zkdist.msm_sharded(bases, d_cols[c], montgomery=True, window_bits=a.window_bits, stream=e.st) for c in range(NCOL)]
-        else:
-            outs = e.zkdist.msm_batch_sharded(bases, d_cols, montgomery=True, window_bits=a.window_bits, stream=e.st)
+            for c in range(NCOL):
+                chain(c, d_cols[c], side.cuda_stream)
+        result["commitments"] = commit_batch(g_lagrange, d_cols)
         main.wait_stream(side)
-        result["commitments"] = outs
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        # ---- 2 lookup
+        commit_batch(g_lagrange, d_lookup[2:4])
+        zk.halo2.lookup_product(sfield, d_lookup[0], d_lookup[1], d_lookup[2], d_lookup[3], beta, gamma, d_zl, stream=e.st)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            chain(NCOL, d_lookup[2], side.cuda_stream)
+            chain(NCOL + 1, d_lookup[3], side.cuda_stream)
+            chain(NCOL + 2, d_zl, side.cuda_stream)
+        e.zkdist.msm_sharded(g_lagrange, d_zl, montgomery=True, window_bits=a.window_bits, stream=e.st)
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        # ---- 3 permutation: chunk c + 1 continues from the last value of chunk c
+        z_first = None
+        pcols = [d_cols[c % NCOL] for c in range(N_PERM_COLS)]
+        for c in range(3):
+            lo, hi = c * PERM_CHUNK, min(N_PERM_COLS, (c + 1) * PERM_CHUNK)
+            z_first = zk.halo2.permutation_product(sfield, pcols[lo:hi], d_sigma[lo:hi], beta, gamma, delta, k, d_zp[c], first_column_index=lo,
+                                                   z_first=z_first, stream=e.st)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for c in range(3):
+                chain(NCOL + 3 + c, d_zp[c], side.cuda_stream)
+        commit_batch(g_lagrange, torch.stack(d_zp))
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        # ---- 4 quotient
+        e.zkdist.msm_sharded(g_coeff, d_rand, montgomery=True, window_bits=a.window_bits, stream=e.st)
+        ext_cols = [d_ext[c] for c in range(NCOL)] + d_fixed_ext + [d_ext[NCOL + c] for c in range(6)]
+        zk.halo2.evaluate_expression(sfield, prog, ext_cols, consts, ext, 1 << (ext - k), d_h, stream=e.st)
+        dom.divide_by_vanishing_poly(d_h, stream=e.st)
+        dom.extended_to_coeff(d_h, stream=e.st)
+        commit_batch(g_coeff, d_h.view(N_H_PIECES, n, 4))
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        # ---- 5 opening: the inner-product argument (the combined polynomial stands in: one of the coefficient vectors)
+        d_ipa[0].copy_(d_h[:n])
+        d_ipa[1].copy_(d_ext[0][:n])
+        d_g.copy_(d_pts_c)
+        ipa = zk.halo2.IpaProver(curve, d_ipa[0], d_ipa[1], d_g, stream=e.st)
+        for j in range(k):
+            ipa.round(sharded=e.world > 1)
+            ipa.fold(us[j])
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        if timed_:
+            for name, dt in zip(phase_ms, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                phase_ms[name] += dt * 1e3
 
     elapsed = timed(e, step)
     if e.rank == 0:
         prof = zk.msm_last_profile()
         m = e.msm_tot
+        n_msm = NCOL + 3 + 3 + 1 + N_H_PIECES
         line = base_line(e, n * a.steps / elapsed, elapsed,
-                         "halo2 prover GPU work-list, 2^%d rows (BASELINE configs[2]): 13 x commit (%s MSM 2^%d) + 13 x lagrange_to_coeff (iNTT 2^%d) "
-                         "+ 13 x coeff_to_extended (NTT 2^%d) + 1 x extended_to_coeff (iNTT 2^%d)" % (k, curve, k, k, ext, ext),
-                         {"rows_per_step": n, "msm_curve": curve, "msm_points": n, "msm_windows_done": prof["windows_done"],
-                          "msm_windows": prof["windows_total"], "window_bits": prof["window_bits"], "columns": NCOL,
-                          "streams": "one (serial)" if a.serial else "MSM batch on two library streams + NTT chain on a third"})
-        line["msm_ms"] = m["device_ms"] / max(1, m["msms"])
-        line["msm_mops"] = n / (line["msm_ms"] * 1e-3) / 1e6 * (prof["windows_total"] / max(1, prof["windows_done"]))
-        line["msm_phases_ms"] = {kk: m[kk] / max(1, m["msms"]) for kk in ("sort_ms", "accumulate_kernel_ms", "accumulate_ms", "reduce_ms", "host_tail_ms")}
+                         "halo2 create_proof device work-list, 2^%d rows, the reference circuit's column layout (BASELINE configs[2]): advice 13 x (commit + l2c + c2e) ; "
+                         "lookup 3 commits + product + 3 NTT chains ; permutation 3 products + 3 commits + 3 NTT chains ; quotient: random-poly commit, "
+                         "%d-op expression over 27 extended columns, divide by Z_H, extended_to_coeff, 8 h-piece commits ; opening: %d-round IPA "
+                         "(2 MSMs + 2 inner products + 3 folds per round)" % (k, len(prog), k),
+                         {"rows_per_step": n, "msm_curve": curve, "msm_points": n, "msm_windows_done": 16, "msm_windows": 16,
+                          "window_bits": 16, "columns": NCOL, "full_size_msms_per_step": n_msm, "ntt_2p%d_per_step" % k: 19, "ntt_2p%d_per_step" % ext: 20,
+                          "streams": "one (serial)" if a.serial else "MSM batches on two library streams + NTT chains on a third",
+                          "not_in_list": "evaluations at x, multiopen combination (vector ops on resident data); RNG, transcript, lookup sort (CPU)"})
+        line["phases_ms"] = {kk: v / a.steps for kk, v in phase_ms.items()}
+        line["msm_ms_mean_all_sizes"] = m["device_ms"] / max(1, m["msms"])
+        line["msms_per_step"] = m["msms"] / a.steps
         line["ntt_kernel_ms_per_step"] = e.ntt_tot["kernel_ms"] / a.steps
+        line["accumulate_kernel_ms_per_step"] = m["accumulate_kernel_ms"] / a.steps
         if not a.no_cpu_baseline and e.world == 1:
-            line["cpu_baseline"] = cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, cols_host[0], result["commitments"][0])
-        emit(e, line, rooflines(e, "halo2_2p%d" % k))
+            line["cpu_baseline"] = cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, cols_host[0], result["commitments"][0], sum(1 for o in prog if o[0] in ("mul", "scale")))
+        roofs = rooflines(e, "halo2_2p%d" % k)
+        if "msm_accumulate_kernel" in roofs:     # the IPA's small MSMs are in the totals: per-launch figures are means over all sizes
+            roofs["msm_accumulate_kernel"]["note"] += "; launches include the 2 x %d shrinking MSMs of the IPA (means over all sizes)" % k
+        line["config"].pop("msm_curve")
+        emit(e, line, roofs)
 
 
-def cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, col0, gpu_commit0):
-    """The oracle ('port': CPU restatement of halo2_proofs 0.2 best_multiexp -- chunk per thread over ALL host cores -- and
-    best_fft) timed on this box on a bounded sample of the same work-list: ONE column's commitment, ONE iNTT 2^k and ONE
-    NTT 2^(k+3); the step is 13 x (msm + ntt_k + ntt_ext) + ntt_ext.  ark-ec's window-parallel Pippenger is timed beside
-    it and the FASTER of the two MSMs is used.  Also a last bit-exact check of the GPU's first commitment."""
+def cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, col0, gpu_commit0, n_expr_muls):
+    """The oracle ('port': CPU restatements of halo2_proofs 0.2 best_multiexp -- chunk per thread over ALL host cores -- ,
+    best_fft, and per-element field / curve arithmetic) timed on this box on a bounded sample of the same work-list:
+    ONE commitment, ONE iNTT 2^k, ONE NTT 2^(k+3), 2^16 field products (grand products / expression), 2^12 point
+    multiplications (the IPA generator fold); the step is assembled from the counts of each kind, with perfect scaling
+    over the cores assumed for the per-element work.  ark-ec's window-parallel Pippenger is timed beside the chunked
+    one and the FASTER MSM is used.  Also a last bit-exact check of the GPU's first commitment."""
     from oracle import zk_oracle as orc
     np, zk = e.np, e.zk
     cores = os.cpu_count() or 1
@@ -316,13 +453,28 @@ def cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, col0, gpu_commit0):
     t0 = time.perf_counter()
     orc.halo2_best_fft(sfield, big, w_ext, ext, threads=cores)
     t_e = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.to_mont(sfield, col0[: 1 << 16])                       # one Montgomery product per element, one thread
+    t_mul = (time.perf_counter() - t0) / (1 << 16)
+    ks = e.synth.scalars_for(curve, 1 << 12, 77)
+    t0 = time.perf_counter()
+    orc.fixed_base_mul(curve, ks, threads=cores)               # 255-bit double-and-add per point, all cores
+    t_pmul = (time.perf_counter() - t0) / (1 << 12)
     t_msm = min(t_h2, t_ark)
-    t_step = NCOL * (t_msm + t_n + t_e) + t_e
+    n_msm, n_ntt_k, n_ntt_e = NCOL + 3 + 3 + 1 + N_H_PIECES, 19, 20
+    muls_products = n * (4 * 8 + 3 * (4 * PERM_CHUNK + 8))      # factors, batched inversion, scan: lookup + three permutation chunks
+    muls_expr = (1 << ext) * n_expr_muls                       # the products of the quotient program, at every row of the extended domain
+    t_field = (muls_products + muls_expr) * t_mul / cores
+    # IPA: MSMs of 2 * (n/2 + n/4 + ...) = 2n points ~ two full MSMs; n point multiplications for the generator folds
+    t_ipa = 2 * t_msm + n * t_pmul
+    t_step = n_msm * t_msm + n_ntt_k * t_n + n_ntt_e * t_e + t_field + t_ipa
     ok = bool((zk.point_to_affine(curve, gpu_commit0) == exp).all() and (exp == exp_ark).all())
     return {"value": n / t_step, "unit": "constraints/s", "cores": cores, "kind": "port",
-            "sample": "1 of the 13 columns: best_multiexp 2^%d (halo2 chunk-per-thread, %d threads: %.3f s; ark window-parallel, %d threads: %.3f s; "
-                      "faster one used) + best_fft 2^%d (%.3f s) + best_fft 2^%d (%.3f s), %d threads; step = 13 x (msm + fft + ext fft) + ext fft = %.2f s"
-                      % (k, cores, t_h2, ark_threads, t_ark, k, t_n, ext, t_e, cores, t_step),
+            "sample": "best_multiexp 2^%d (halo2 chunk-per-thread, %d threads: %.3f s; ark window-parallel, %d threads: %.3f s; faster one used) ; best_fft 2^%d %.3f s, "
+                      "2^%d %.3f s (%d threads) ; field product %.0f ns (one thread) ; point multiplication %.1f us per point on %d threads ; "
+                      "step = %d MSMs + %d + %d FFTs + %.2g products / %d cores + IPA (2 MSM + 2^%d point multiplications) = %.2f s"
+                      % (k, cores, t_h2, ark_threads, t_ark, k, t_n, ext, t_e, cores, t_mul * 1e9, t_pmul * 1e6, cores, n_msm, n_ntt_k, n_ntt_e,
+                         muls_products + muls_expr, cores, k, t_step),
             "msm_mops": n / t_msm / 1e6, "msm_s": {"halo2_chunked": t_h2, "ark_window_parallel": t_ark}, "gpu_result_matches": ok}
 
 

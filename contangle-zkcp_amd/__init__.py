@@ -33,7 +33,7 @@ EXPORTS = [
     "zk_point_add", "zk_point_to_affine", "zk_fixed_base_mul_device", "zk_vec_op_device", "zk_groth16_witness_map_device",
     "zk_fixed_base_msm_device", "zk_ntt_extend_device", "zk_init_devices", "zk_device_count", "zk_msm_submit", "zk_msm_collect",
     "zk_msm_batch_device", "zk_ntt_configure", "zk_msm_profile_totals", "zk_ntt_profile_enable", "zk_ntt_profile_read",
-    "zk_field_modulus", "zk_vec_scale_periodic_device",
+    "zk_field_modulus", "zk_vec_scale_periodic_device", "zk_bases_refresh",
 ]
 
 
@@ -48,7 +48,7 @@ class MsmOpts(ctypes.Structure):
     _fields_ = [("window_bits", ctypes.c_int), ("window_begin", ctypes.c_int), ("window_end", ctypes.c_int),
                 ("limb_bits", ctypes.c_int), ("split_log_plus1", ctypes.c_int), ("slice_len", ctypes.c_int),
                 ("big_threshold", ctypes.c_int), ("waves_per_simd", ctypes.c_int), ("flags", ctypes.c_int),
-                ("reserved", ctypes.c_int * 3)]
+                ("base_offset", ctypes.c_int), ("reserved", ctypes.c_int * 2)]
 
 
 MSM_FLAG_NO_HOT_HELP = 1
@@ -56,7 +56,7 @@ MSM_FLAG_NO_HOT_HELP = 1
 
 class NttOpts(ctypes.Structure):
     _fields_ = [("max_log_radix", ctypes.c_int), ("log_tile_plus1", ctypes.c_int), ("block", ctypes.c_int),
-                ("reserved", ctypes.c_int)]
+                ("limb_bits", ctypes.c_int)]
 
 
 class MsmProfile(ctypes.Structure):
@@ -94,6 +94,7 @@ def load(path=None):
     lib.zk_bases_upload.argtypes = [i32, vp, u64, ctypes.POINTER(u64)]
     lib.zk_bases_adopt_device.argtypes = [i32, vp, u64, ctypes.POINTER(u64)]
     lib.zk_bases_free.argtypes = [u64]
+    lib.zk_bases_refresh.argtypes = [u64, u64, u64, vp]
     lib.zk_msm.argtypes = [i32, u64, vp, u64, i32, ctypes.POINTER(MsmOpts), vp]
     lib.zk_msm_device.argtypes = [i32, u64, vp, u64, i32, ctypes.POINTER(MsmOpts), vp, vp]
     lib.zk_msm_last_profile.argtypes = [ctypes.POINTER(MsmProfile)]
@@ -264,6 +265,10 @@ class Bases:
             _check(load().zk_bases_upload(self.curve, _ptr(pts), self.n, ctypes.byref(h)), "zk_bases_upload")
         self.handle = h.value
 
+    def refresh(self, offset, count, stream=0):
+        """points [offset, offset + count) of the adopted device buffer were rewritten on `stream`: update the derived copies"""
+        _check(load().zk_bases_refresh(self.handle, offset, count, ctypes.c_void_p(stream)), "zk_bases_refresh")
+
     def free(self):
         if self.handle:
             _check(load().zk_bases_free(self.handle), "zk_bases_free")
@@ -277,7 +282,7 @@ class Bases:
 
 
 def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len=0, big_threshold=0, waves_per_simd=0,
-             no_hot_help=False):
+             no_hot_help=False, base_offset=0):
     o = MsmOpts()
     o.window_bits = window_bits
     if windows is not None:
@@ -288,6 +293,7 @@ def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len
     o.big_threshold = big_threshold
     o.waves_per_simd = waves_per_simd
     o.flags = MSM_FLAG_NO_HOT_HELP if no_hot_help else 0
+    o.base_offset = base_offset
     return o
 
 

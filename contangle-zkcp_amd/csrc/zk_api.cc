@@ -101,6 +101,7 @@ MsmTuning tuning_from(const zk_msm_opts* o) {
     t.big_thresh = o->big_threshold > 0 ? (uint32_t)o->big_threshold : 0;
     t.waves = o->waves_per_simd;
     t.no_hot_help = (o->flags & ZK_MSM_FLAG_NO_HOT_HELP) != 0;
+    t.base_offset = o->base_offset > 0 ? (uint64_t)o->base_offset : 0;
     return t;
 }
 
@@ -266,12 +267,14 @@ int collect_job(MsmJob& job, void* out) {
     return status;
 }
 
-int find_bases(uint64_t handle, zk_curve_t c, uint64_t n, const BasesEntry** out) {
+int find_bases(uint64_t handle, zk_curve_t c, uint64_t n, const BasesEntry** out, const zk_msm_opts* opts = nullptr) {
     std::lock_guard<std::mutex> lk(g.mu);
     ZK_TRY(require_init());
     auto it = g.bases.find(handle);
     if (it == g.bases.end()) return ZK_ERR_BAD_HANDLE;
-    if (it->second.curve != (int)c || n > it->second.n) return ZK_ERR_INVALID_ARG;
+    const uint64_t off = opts && opts->base_offset > 0 ? (uint64_t)opts->base_offset : 0;
+    if (opts && opts->base_offset < 0) return ZK_ERR_INVALID_ARG;
+    if (it->second.curve != (int)c || n > it->second.n || off > it->second.n - n) return ZK_ERR_INVALID_ARG;
     *out = &it->second;   // entries are only erased by zk_bases_free, which the caller must not race with a running MSM
     return ZK_OK;
 }
@@ -579,11 +582,48 @@ API int zk_bases_free(uint64_t handle) {
     return ZK_OK;
 }
 
+API int zk_bases_refresh(uint64_t handle, uint64_t offset, uint64_t count, void* stream) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    ZK_TRY(require_init());
+    auto it = g.bases.find(handle);
+    if (it == g.bases.end()) return ZK_ERR_BAD_HANDLE;
+    BasesEntry& be = it->second;
+    if (offset > be.n || count > be.n - offset) return ZK_ERR_INVALID_ARG;
+    size_t esz = 0;
+    const zk_curve_t c = (zk_curve_t)be.curve;
+    CURVE_SWITCH(c, esz = sizeof(Affine<C>));
+    int src = -1;
+    for (size_t d = 0; d < be.per_dev.size(); d++)
+        if (!be.per_dev[d].owned) src = (int)d;          // the adopted copy is the one the caller rewrites
+    if (src < 0) src = 0;
+    for (size_t d = 0; d < be.per_dev.size(); d++) {
+        DeviceCtx& dc = *g.devs[d];
+        ZK_TRY(bind_device(dc));
+        hipStream_t st = (hipStream_t)stream;
+        if ((int)d != src) {      // a peer: wait for the caller's stream, copy the range over, convert on the library's stream
+            HIP_TRY(hipSetDevice(g.devs[src]->device));
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            HIP_TRY(hipSetDevice(dc.device));
+#if defined(ZK_EMU)
+            HIP_TRY(hipMemcpy((unsigned char*)be.per_dev[d].dev + offset * esz, (unsigned char*)be.per_dev[src].dev + offset * esz, count * esz, hipMemcpyDeviceToDevice));
+#else
+            HIP_TRY(hipMemcpyPeer((unsigned char*)be.per_dev[d].dev + offset * esz, dc.device, (unsigned char*)be.per_dev[src].dev + offset * esz,
+                                  g.devs[src]->device, count * esz));
+#endif
+            st = nullptr;
+        }
+        CURVE_SWITCH(c, ZK_TRY(bases_refresh_run<C>(be.per_dev[d], offset, count, st)));
+        if ((int)d != src) HIP_TRY(hipStreamSynchronize(nullptr));
+    }
+    hipSetDevice(g.devs[0]->device);
+    return ZK_OK;
+}
+
 API int zk_msm_submit(zk_curve_t c, uint64_t handle, const void* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts, void* stream,
                       uint64_t* ticket_out) {
     if (!ticket_out || (n && (!d_scalars || !aligned16(d_scalars)))) return ZK_ERR_INVALID_ARG;
     const BasesEntry* be = nullptr;
-    ZK_TRY(find_bases(handle, c, n, &be));
+    ZK_TRY(find_bases(handle, c, n, &be, opts));
     DeviceCtx& dc = device_of(d_scalars);
     ZK_TRY(bind_device(dc));
     MsmJob* job = nullptr;
@@ -615,7 +655,7 @@ API int zk_msm_device(zk_curve_t c, uint64_t handle, const void* d_scalars, uint
                       void* out, void* stream) {
     if (!out || (n && (!d_scalars || !aligned16(d_scalars)))) return ZK_ERR_INVALID_ARG;
     const BasesEntry* be = nullptr;
-    ZK_TRY(find_bases(handle, c, n, &be));
+    ZK_TRY(find_bases(handle, c, n, &be, opts));
     const MsmTuning tu = tuning_from(opts);
     DeviceCtx& dc = device_of(d_scalars);
     if (g.devs.size() > 1 && whole_msm(tu) && n > 0) return msm_fanout(c, *be, d_scalars, &dc, (hipStream_t)stream, n, mont ? 1 : 0, tu, out);
@@ -632,7 +672,7 @@ API int zk_msm(zk_curve_t c, uint64_t handle, const void* scalars_host, uint64_t
                void* out) {
     if (!out || (n && !scalars_host)) return ZK_ERR_INVALID_ARG;
     const BasesEntry* be = nullptr;
-    ZK_TRY(find_bases(handle, c, n, &be));
+    ZK_TRY(find_bases(handle, c, n, &be, opts));
     const MsmTuning tu = tuning_from(opts);
     if (g.devs.size() > 1 && whole_msm(tu) && n > 0) return msm_fanout(c, *be, scalars_host, nullptr, nullptr, n, mont ? 1 : 0, tu, out);
     DeviceCtx& dc = *g.devs[0];
@@ -650,7 +690,7 @@ API int zk_msm_batch_device(zk_curve_t c, uint64_t handle, const void* d_scalars
     if (count == 0) return ZK_OK;
     if (!out || stride_elems < n || (n && (!d_scalars || !aligned16(d_scalars)))) return ZK_ERR_INVALID_ARG;
     const BasesEntry* be = nullptr;
-    ZK_TRY(find_bases(handle, c, n, &be));
+    ZK_TRY(find_bases(handle, c, n, &be, opts));
     const MsmTuning tu = tuning_from(opts);
     DeviceCtx& dc = device_of(d_scalars);
     ZK_TRY(bind_device(dc));

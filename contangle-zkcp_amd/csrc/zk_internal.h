@@ -75,6 +75,7 @@ struct MsmTuning {
     int limb_bits = 0;        // 32 forces the saturated path
     int waves = 0;
     bool no_hot_help = false;
+    uint64_t base_offset = 0;
 };
 
 // One MSM in flight: its own device workspaces (so two jobs on two streams never share a buffer), a pinned host buffer

@@ -308,14 +308,25 @@ int bases_prepare_run(BasesCopy& bc, uint64_t n) {
     return ZK_OK;
 }
 
+template <class C>
+int bases_refresh_run(const BasesCopy& bc, uint64_t offset, uint64_t count, hipStream_t st) {
+    if constexpr (has_f29<C>()) {
+        if (!bc.dev29 || count == 0) return ZK_OK;
+        ZK_LAUNCH((bases_to29_kernel<C>), (unsigned)((count + 255) / 256), 256, 0, st, (const Affine<C>*)bc.dev + offset,
+                  (StoredAffine<F29View<C>>*)bc.dev29 + offset, count);
+        HIP_TRY(hipGetLastError());
+    }
+    return ZK_OK;
+}
+
 // every curve runs its bucket arithmetic in the lazy-limb view unless opts.limb_bits = 32 asks for the saturated words
 template <class C>
 int msm_enqueue(MsmJob& job, const BasesCopy& bc, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
     if constexpr (has_f29<C>()) {
         if (bc.dev29 && tu.limb_bits != 32)
-            return msm_enqueue_impl<C, F29View<C>>(job, (const StoredAffine<F29View<C>>*)bc.dev29, d_scalars, n, mont, tu);
+            return msm_enqueue_impl<C, F29View<C>>(job, (const StoredAffine<F29View<C>>*)bc.dev29 + tu.base_offset, d_scalars, n, mont, tu);
     }
-    return msm_enqueue_impl<C, C>(job, (const Affine<C>*)bc.dev, d_scalars, n, mont, tu);
+    return msm_enqueue_impl<C, C>(job, (const Affine<C>*)bc.dev + tu.base_offset, d_scalars, n, mont, tu);
 }
 
 template <class C>
@@ -342,6 +353,94 @@ int fixed_base_msm_run(DeviceCtx& dc, const Affine<C>& base, const Fe<typename C
     HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
+// ---- GLV decomposition of the fold's shared scalar (host, 64-bit limbs; constants from tools/gen_glv.py) ----
+namespace glv {
+inline void mul_lo256(uint64_t* r, const uint64_t* a, const uint64_t* b) {   // (a * b) mod 2^256
+    uint64_t t[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        unsigned __int128 c = 0;
+        for (int j = 0; i + j < 4; j++) {
+            c += (unsigned __int128)a[i] * b[j] + t[i + j];
+            t[i + j] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    for (int i = 0; i < 4; i++) r[i] = t[i];
+}
+inline void sub256(uint64_t* r, const uint64_t* a, const uint64_t* b) {
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; i++) {
+        unsigned __int128 x = (unsigned __int128)a[i] - b[i] - (uint64_t)br;
+        r[i] = (uint64_t)x;
+        br = (x >> 64) & 1;
+    }
+}
+inline void neg256(uint64_t* r, const uint64_t* a) {
+    const uint64_t z[4] = {0, 0, 0, 0};
+    sub256(r, z, a);
+}
+// c = (k * g) >> 384 for k < 2^256, g < 2^320
+inline void mulhi384(uint64_t* c, const uint64_t* k, const uint64_t* g5) {
+    uint64_t t[9] = {0};
+    for (int i = 0; i < 4; i++) {
+        unsigned __int128 cy = 0;
+        for (int j = 0; j < 5; j++) {
+            cy += (unsigned __int128)k[i] * g5[j] + t[i + j];
+            t[i + j] = (uint64_t)cy;
+            cy >>= 64;
+        }
+        t[i + 5] = (uint64_t)cy;
+    }
+    c[0] = t[6];
+    c[1] = t[7];
+    c[2] = t[8];
+    c[3] = 0;
+}
+}  // namespace glv
+
+template <class C>
+bool glv_decompose(const Fe<typename C::Fr>& u_canonical, FoldScalar& out) {
+    if constexpr (Glv<C>::HAS) {
+        using G = Glv<C>;
+        uint64_t k[4], c1[4], c2[4], t[4], k1[4], k2[4];
+        for (int i = 0; i < 4; i++) k[i] = (uint64_t)u_canonical.v[2 * i] | ((uint64_t)u_canonical.v[2 * i + 1] << 32);
+        glv::mulhi384(c1, k, G::G1);
+        glv::mulhi384(c2, k, G::G2);
+        if (G::G1_NEG) glv::neg256(c1, c1);
+        if (G::G2_NEG) glv::neg256(c2, c2);
+        // k1 = k - c1 a1 - c2 a2 ; k2 = -c1 b1 - c2 b2      (mod 2^256, two's complement; the results are ~129-bit)
+        glv::mul_lo256(t, c1, G::A1);
+        glv::sub256(k1, k, t);
+        glv::mul_lo256(t, c2, G::A2);
+        glv::sub256(k1, k1, t);
+        glv::mul_lo256(k2, c1, G::B1);
+        glv::mul_lo256(t, c2, G::B2);
+        {
+            unsigned __int128 cy = 0;
+            for (int i = 0; i < 4; i++) {
+                cy += (unsigned __int128)k2[i] + t[i];
+                k2[i] = (uint64_t)cy;
+                cy >>= 64;
+            }
+        }
+        glv::neg256(k2, k2);
+        out.neg1 = (int)(k1[3] >> 63);
+        out.neg2 = (int)(k2[3] >> 63);
+        if (out.neg1) glv::neg256(k1, k1);
+        if (out.neg2) glv::neg256(k2, k2);
+        if (k1[3] | k2[3] | (k1[2] >> 2) | (k2[2] >> 2)) return false;   // not short: fall back to the plain chain
+        for (int i = 0; i < 4; i++) {
+            out.k1[2 * i] = (uint32_t)k1[i];
+            out.k1[2 * i + 1] = (uint32_t)(k1[i] >> 32);
+            out.k2[2 * i] = (uint32_t)k2[i];
+            out.k2[2 * i + 1] = (uint32_t)(k2[i] >> 32);
+        }
+        out.glv = 1;
+        return true;
+    }
+    return false;
+}
+
 // g[i] <- affine(g[i] + [u] g[i + half]) for i < half (u canonical)
 template <class C>
 int ipa_fold_bases_run(DeviceCtx& dc, Affine<C>* gens, uint64_t half, const Fe<typename C::Fr>& u_canonical, hipStream_t st) {
@@ -351,13 +450,19 @@ int ipa_fold_bases_run(DeviceCtx& dc, Affine<C>* gens, uint64_t half, const Fe<t
     ZK_TRY(stream_scratch(dc, st, &ss));
     ZK_TRY(ws_get(ss->fb_tmp, (size_t)half * sizeof(XYZZ<C>)));
     XYZZ<C>* tmp = (XYZZ<C>*)ss->fb_tmp.p;
-    int top = -1;
-    for (int b = 32 * C::Fr::N - 1; b >= 0; b--)
-        if ((u_canonical.v[b >> 5] >> (b & 31)) & 1) {
-            top = b;
+    FoldScalar ks;
+    memset(&ks, 0, sizeof ks);
+    if (!glv_decompose<C>(u_canonical, ks)) {
+        memset(&ks, 0, sizeof ks);
+        for (int i = 0; i < C::Fr::N && i < 8; i++) ks.k1[i] = u_canonical.v[i];
+    }
+    ks.top_bit = -1;
+    for (int b = 255; b >= 0; b--)
+        if (((ks.k1[b >> 5] | ks.k2[b >> 5]) >> (b & 31)) & 1) {
+            ks.top_bit = b;
             break;
         }
-    ZK_LAUNCH((ipa_fold_bases_kernel<C>), (unsigned)((half + 63) / 64), 64, 0, st, (const Affine<C>*)gens, tmp, (uint32_t)half, u_canonical, top);
+    ZK_LAUNCH((ipa_fold_bases_kernel<C>), (unsigned)((half + 63) / 64), 64, 0, st, (const Affine<C>*)gens, tmp, (uint32_t)half, ks);
     const uint64_t lanes = (half + FB_K - 1) / FB_K;
     ZK_LAUNCH((xyzz_batch_to_affine_kernel<C>), (unsigned)((lanes + 63) / 64), 64, 0, st, (const XYZZ<C>*)tmp, gens, (uint32_t)half);
     HIP_TRY(hipGetLastError());

@@ -12,6 +12,7 @@
 // (zk_rt.h first: it brings in the HIP runtime or the test emulator)
 #include "zk_curve.h"
 #include "zk_curve29.h"
+#include "zk_glv_params.h"
 
 namespace zk {
 
@@ -980,23 +981,48 @@ __global__ void __launch_bounds__(64) fixed_base_mul_kernel(const Fe<typename C:
 }
 
 // halo2_proofs 0.2 poly/commitment/prover.rs parallel_generator_collapse (one IPA round): tmp[i] = g[i] + [u] g[i + half].
-// The challenge u is the same for every lane (canonical words in SGPRs), so the double-and-add has wave-uniform control
-// flow; xyzz_batch_to_affine_kernel then writes the folded generators back as affine points (batch_normalize upstream).
+// The challenge u is the same for every lane, so the scalar multiplication has wave-uniform control flow; it runs on lazy
+// limbs like the buckets.  On the Pasta curves (j = 0) u is split as k1 + k2 lambda with |k1|, |k2| < 2^129 (host side) and
+// [u] P = [k1] P + [k2] phi(P), phi(x, y) = (beta x, y): one joint chain of ~129 doublings instead of 255, ~129 additions.
+// xyzz_batch_to_affine_kernel then writes the folded generators back as affine points (batch_normalize upstream).
+struct FoldScalar {
+    uint32_t k1[8], k2[8];   // magnitudes (k2 = 0, k1 = u without GLV)
+    int neg1, neg2;          // use -P / -phi(P)
+    int top_bit;             // highest set bit of k1 | k2, -1 when both are zero
+    int glv;
+};
 template <class C>
-__global__ void __launch_bounds__(64) ipa_fold_bases_kernel(const Affine<C>* __restrict__ g, XYZZ<C>* __restrict__ tmp, uint32_t half,
-                                                            Fe<typename C::Fr> u, int top_bit) {
-    using Fr = typename C::Fr;
+__global__ void __launch_bounds__(64) ipa_fold_bases_kernel(const Affine<C>* __restrict__ g, XYZZ<C>* __restrict__ tmp, uint32_t half, FoldScalar ks) {
+    using CK = F29View<C>;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
-    const Affine<C> hi = g[i + half], lo = g[i];
-    XYZZ<C> acc;
+    const Affine<C> hi_std = g[i + half], lo_std = g[i];
+    Affine<CK> p1, p2, lo;
+    aff29_from_std(p1, hi_std);
+    aff29_from_std(lo, lo_std);
+    aff_neg_if(p1, ks.neg1 != 0);
+    p2 = p1;
+    if constexpr (Glv<C>::HAS) {
+        if (ks.glv) {
+            Affine<C> q = hi_std;       // phi(P) = (beta x, y); the identity (0, 0) stays (0, 0)
+            Coord<C> beta;
+            fe_from_words(beta, Glv<C>::BETA);
+            fe_mul(q.x, q.x, beta);
+            aff29_from_std(p2, q);
+            aff_neg_if(p2, ks.neg2 != 0);
+        }
+    }
+    XYZZ<CK> acc;
     xyzz_set_inf(acc);
-    for (int bit = top_bit; bit >= 0; bit--) {
+    for (int bit = ks.top_bit; bit >= 0; bit--) {
         xyzz_dbl(acc);
-        if ((word_at<Fr::N>(u.v, bit >> 5) >> (bit & 31)) & 1) xyzz_add_mixed(acc, hi);
+        if ((word_at<8>(ks.k1, bit >> 5) >> (bit & 31)) & 1) xyzz_add_mixed(acc, p1);
+        if ((word_at<8>(ks.k2, bit >> 5) >> (bit & 31)) & 1) xyzz_add_mixed(acc, p2);
     }
     xyzz_add_mixed(acc, lo);
-    tmp[i] = acc;
+    XYZZ<C> r;
+    xyzz29_to_std<C>(r, acc);
+    tmp[i] = r;
 }
 
 // ------------------------------------------------------------------------------------------

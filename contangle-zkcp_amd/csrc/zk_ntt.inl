@@ -162,7 +162,7 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
     if (logn > (uint32_t)F::TWO_ADICITY || logn > 30) return ZK_ERR_INVALID_ARG;   // before anything is sized from logn
     if (logn == 0) return ZK_OK;  // size-1 transform is the identity, n^-1 = 1 and g^0 = 1
     // lazy 29-bit limbs inside the tiles (zk_ntt29_kernels.h) unless zk_ntt_opts asks for the saturated words
-    const bool lazy = g.ntt_opts.reserved != 32;
+    const bool lazy = g.ntt_opts.limb_bits != 32;
     PowTables<F> tpre{nullptr, nullptr}, tpost{nullptr, nullptr};
     if (g_pre) ZK_TRY(pow_tables<F>(dc, *g_pre, logn, field, st, &tpre, lazy));
     if (g_post) ZK_TRY(pow_tables<F>(dc, *g_post, logn, field, st, &tpost, lazy));

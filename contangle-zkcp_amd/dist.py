@@ -85,11 +85,13 @@ def msm_batch_sharded(bases, d_cols, montgomery=False, window_bits=0, group=None
 
 
 def msm_many_sharded(jobs, window_bits=0, group=None, stream=0):
-    """jobs: [(bases, device scalars, montgomery)] with different bases (the five MSMs of a Groth16 proof): every MSM is
+    """jobs: [(bases, device scalars, montgomery[, base_offset])] with different bases (the five MSMs of a Groth16 proof): every MSM is
     submitted before the first is collected (deferred results), then one all_gather combines the ranks' partials"""
     world, rank = _world(group)
     tickets, curves = [], []
-    for bases, sc, mont in jobs:
+    for job in jobs:
+        bases, sc, mont = job[:3]
+        base_offset = job[3] if len(job) > 3 else 0
         n = int(sc.shape[0])
         lo, hi = window_range(msm_window_count(bases.curve, n, window_bits), rank, world)
         curves.append(bases.curve)
@@ -102,7 +104,7 @@ def msm_many_sharded(jobs, window_bits=0, group=None, stream=0):
                     tickets[i] = t.collect()
                     break
         tickets.append(msm_submit(bases, sc, montgomery=mont, window_bits=window_bits, windows=(lo, hi) if world > 1 else None,
-                                  stream=stream))
+                                  stream=stream, base_offset=base_offset))
     parts = []
     for c, t in zip(curves, tickets):
         parts.append(_identity(c) if t is None else (t if isinstance(t, np.ndarray) else t.collect()))

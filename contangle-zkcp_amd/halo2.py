@@ -236,22 +236,29 @@ class IpaProver:
 
     def __init__(self, curve, d_p, d_b, d_g, stream=0):
         """d_p, d_b: device buffers [n, 4] (p' coefficients and the powers of x_3, Montgomery); d_g: [n, 2 * limbs] affine
-        generators (a working copy: it is folded in place)"""
+        generators (a working copy: it is folded in place).  The generator vector is adopted ONCE as a bases handle; every
+        round's two MSMs address its halves through zk_msm_opts.base_offset, and the fold refreshes the handle's derived
+        copy for the half that survives."""
         self.curve, self.field = curve_id(curve), scalar_field(curve)
         self.p, self.b, self.g, self.stream = d_p, d_b, d_g, stream
         self.n = int(d_p.shape[0])
         assert self.n & (self.n - 1) == 0 and int(d_b.shape[0]) == self.n and int(d_g.shape[0]) == self.n
+        self.bases = Bases(self.curve, device_tensor=d_g, n=self.n)
 
-    def round(self):
+    def round(self, sharded=False):
+        """sharded: every rank of a torch.distributed job holds the same p', b, G' and sums its own scalar windows of the
+        two MSMs; one all_gather combines them (contangle-zkcp_amd/dist.py)"""
         half = self.n // 2
-        lo, hi = Bases(self.curve, device_tensor=self.g[:half], n=half), Bases(self.curve, device_tensor=self.g[half:self.n], n=half)
-        tl = msm_submit(lo, self.p[half:self.n], montgomery=True, stream=self.stream)          # L = <p'_hi, G'_lo>
-        tr = msm_submit(hi, self.p[:half], montgomery=True, stream=self.stream)                # R = <p'_lo, G'_hi>
+        if sharded:
+            from . import dist as zkdist
+            L, R = zkdist.msm_many_sharded([(self.bases, self.p[half:self.n], True, 0), (self.bases, self.p[:half], True, half)], stream=self.stream)
+        else:
+            tl = msm_submit(self.bases, self.p[half:self.n], montgomery=True, stream=self.stream)                    # L = <p'_hi, G'_lo>
+            tr = msm_submit(self.bases, self.p[:half], montgomery=True, stream=self.stream, base_offset=half)        # R = <p'_lo, G'_hi>
         vl = inner_product(self.field, self.p[half:self.n], self.b[:half], stream=self.stream)
         vr = inner_product(self.field, self.p[:half], self.b[half:self.n], stream=self.stream)
-        L, R = tl.collect(), tr.collect()
-        lo.free()
-        hi.free()
+        if not sharded:
+            L, R = tl.collect(), tr.collect()
         return L, R, vl, vr
 
     def fold(self, u):
@@ -259,4 +266,8 @@ class IpaProver:
         vec_fold(self.field, self.p, half, field_inverse(self.field, u), stream=self.stream)
         vec_fold(self.field, self.b, half, u, stream=self.stream)
         ipa_fold_bases(self.curve, self.g, half, u, stream=self.stream)
+        self.bases.refresh(0, half, stream=self.stream)
         self.n = half
+
+    def free(self):
+        self.bases.free()

@@ -83,7 +83,8 @@ typedef struct {
     int big_threshold;  /* buckets longer than this take the cooperative segment path; 0 = 2 x mean + 64 */
     int waves_per_simd; /* accumulate-kernel waves launched per SIMD; 0 = what the kernel was compiled for */
     int flags;          /* ZK_MSM_FLAG_* */
-    int reserved[3];
+    int base_offset;    /* use bases [base_offset, base_offset + n) of the handle (halo2's IPA works on halves of one generator vector) */
+    int reserved[2];
 } zk_msm_opts;
 #define ZK_MSM_FLAG_NO_HOT_HELP 1   /* skewed witnesses: leave hot regions to their own sort workgroup */
 
@@ -92,7 +93,7 @@ typedef struct {
     int max_log_radix;   /* bits per pass, 1..10; 0 = 10 */
     int log_tile_plus1;  /* 0 = automatic (log2 T = 2); k + 1 forces log2 T = k (k <= 4) */
     int block;           /* lanes per tile workgroup: 64..1024; 0 = 512 */
-    int reserved;
+    int limb_bits;       /* butterflies inside a tile: 0 = lazy 9 x 29-bit limbs (default), 32 = saturated 32-bit words (A/B, tests) */
 } zk_ntt_opts;
 
 /* Wall-clock of the phases of the last zk_msm* call on this process (milliseconds, HIP events).
@@ -145,6 +146,10 @@ int zk_msm_window_count(zk_curve_t c, uint64_t n, int window_bits);         /* c
 int zk_bases_upload(zk_curve_t c, const void *affine_xy_mont_host, uint64_t n, uint64_t *handle_out);
 int zk_bases_adopt_device(zk_curve_t c, const void *affine_xy_mont_dev, uint64_t n, uint64_t *handle_out); /* no copy; caller keeps it alive */
 int zk_bases_free(uint64_t handle);
+/* The caller has rewritten points [offset, offset + count) of an ADOPTED device buffer (on `hip_stream`): bring the library's
+ * derived copies (the lazy-limb form; the peers' copies on a multi-device process) up to date, ordered after that stream's
+ * work.  halo2's IPA folds its generator vector in place every round (zk_ipa_fold_bases_device). */
+int zk_bases_refresh(uint64_t handle, uint64_t offset, uint64_t count, void *hip_stream);
 
 /* ---- MSM: out = sum_i scalars[i] * bases[i], i < n <= bases length ----
  * scalars: n x 4 u64.  scalars_are_montgomery = 0 for ark-ec (canonical BigInt from into_repr()),

@@ -35,7 +35,8 @@ pub struct zk_msm_opts {
     pub big_threshold: c_int,
     pub waves_per_simd: c_int,
     pub flags: c_int,
-    pub reserved: [c_int; 3],
+    pub base_offset: c_int,
+    pub reserved: [c_int; 2],
 }
 #[repr(C)]
 #[derive(Default, Clone, Copy)]
@@ -43,7 +44,7 @@ pub struct zk_ntt_opts {
     pub max_log_radix: c_int,
     pub log_tile_plus1: c_int,
     pub block: c_int,
-    pub reserved: c_int,
+    pub limb_bits: c_int,
 }
 #[repr(C)]
 #[derive(Default, Clone, Copy)]
@@ -151,6 +152,7 @@ extern "C" {
     pub fn zk_bases_upload(c: c_int, affine_xy_mont_host: *const c_void, n: u64, handle_out: *mut u64) -> c_int;
     pub fn zk_bases_adopt_device(c: c_int, affine_xy_mont_dev: *const c_void, n: u64, handle_out: *mut u64) -> c_int;
     pub fn zk_bases_free(handle: u64) -> c_int;
+    pub fn zk_bases_refresh(handle: u64, offset: u64, count: u64, hip_stream: *mut c_void) -> c_int;
     pub fn zk_msm(c: c_int, bases_handle: u64, scalars_host: *const c_void, n: u64, scalars_are_montgomery: c_int,
                   opts: *const zk_msm_opts, out_jacobian_host: *mut c_void) -> c_int;
     pub fn zk_msm_device(c: c_int, bases_handle: u64, scalars_dev: *const c_void, n: u64, scalars_are_montgomery: c_int,

@@ -673,6 +673,8 @@ def check_ipa(zk, cname, k, seed=13):
     x3 = rng.below(r)
     b = [pow(x3, i, r) for i in range(n)]
     us = [1 + rng.below(r - 1) for _ in range(k)]
+    for j, edge in zip(range(k - 1, -1, -1), (r - 1, 1, 0xFFFF, (1 << 200) + 12345)):   # edge challenges on the small rounds
+        us[j] = edge
     rounds, c_fin, b_fin, g_fin = h2.ipa_argument(cname, pp, b, g_py, us)
     ipa = zk.halo2.IpaProver(cname, to_device(zk, _monts(sf, pp)), to_device(zk, _monts(sf, b)), to_device(zk, gens.copy()))
     aff = lambda P: np.zeros(2 * L, dtype=np.uint64) if P is None else np.concatenate([orc.int_to_limbs(pyref.mont(bf, c), L) for c in P])

@@ -558,3 +558,22 @@ def test_ntt_lazy_limbs_extremes(zk):
                     a[::2] = top
                 got = zk.halo2.best_fft(name, a, w, logn)
                 assert (got == orc.halo2_best_fft(name, a, w, logn, threads=16)).all(), (name, logn, pattern)
+
+
+def test_bench_work_lists_run(zk):
+    """bench.py's three work-lists at a small size, one step each, as subprocesses: the JSON line carries the contract's keys
+    (the full-size numbers come from the driver's own run)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (["--logn", "12"], ["--logn", "12", "--serial"], ["--workload", "column", "--logn", "14"],
+                  ["--workload", "groth16", "--curve", "Bls381G1", "--logn", "12"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                    "data", "config", "roofline"):
+            assert key in line, (extra, key)
+        assert line["value"] > 0 and "workload" in line["config"] and line["roofline"]["frac"] > 0

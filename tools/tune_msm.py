@@ -4,10 +4,10 @@ prints phase times."""
 import itertools, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import torch
 import contangle_zkcp_amd as zk
-import parity_suite as ps
+from contangle_zkcp_amd import synth as ps
 
 curve = sys.argv[1] if len(sys.argv) > 1 else "Vesta"
 logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
