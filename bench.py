@@ -82,6 +82,9 @@ def setup():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="NTTs and MSMs on one stream, MSMs one at a time (no overlap)")
     ap.add_argument("--workload", default="halo2", choices=["halo2", "column", "groth16"])
+    ap.add_argument("--ipa", default="virtual", choices=["virtual", "fold"],
+                    help="halo2 work-list, opening: 'virtual' runs every round's two MSMs over the resident SRS (default); 'fold' collapses the "
+                         "generator vector every round as upstream does (one scalar multiplication per surviving point)")
     ap.add_argument("--ntt-limbs", type=int, default=0, choices=[0, 32], help="0: lazy 29-bit limbs inside the NTT tiles (default); 32: saturated words (A/B)")
     args = ap.parse_args()
 
@@ -386,11 +389,17 @@ def bench_halo2(e):
         # ---- 5 opening: the inner-product argument (the combined polynomial stands in: one of the coefficient vectors)
         d_ipa[0].copy_(d_h[:n])
         d_ipa[1].copy_(d_ext[0][:n])
-        d_g.copy_(d_pts_c)
-        ipa = zk.halo2.IpaProver(curve, d_ipa[0], d_ipa[1], d_g, stream=e.st)
+        if a.ipa == "fold":       # upstream's literal structure: collapse the generators every round
+            d_g.copy_(d_pts_c)
+            ipa = zk.halo2.IpaProver(curve, d_ipa[0], d_ipa[1], d_g, stream=e.st)
+        else:                     # L, R over the resident SRS with challenge-weighted scalars: no generator is ever folded
+            ipa = zk.halo2.IpaProverVirtual(curve, d_ipa[0], d_ipa[1], g_coeff, lambda shape: torch.zeros(shape, dtype=torch.int64, device="cuda"),
+                                            stream=e.st)
         for j in range(k):
             ipa.round(sharded=e.world > 1)
             ipa.fold(us[j])
+        if a.ipa == "fold":
+            ipa.free()
         torch.cuda.synchronize()
         t5 = time.perf_counter()
         if timed_:

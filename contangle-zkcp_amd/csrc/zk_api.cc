@@ -1088,6 +1088,22 @@ API int zk_ipa_fold_bases_device(zk_curve_t c, void* g_aff, uint64_t half, const
     });
     return ZK_ERR_INVALID_ARG;
 }
+API int zk_ipa_virtual_scalars_device(zk_field_t f, const void* p, const void* w, uint64_t m0, uint64_t cur, void* sl, void* sr, void* stream) {
+    if (!p || !w || !sl || !sr || !aligned16(p) || !aligned16(w) || !aligned16(sl) || !aligned16(sr)) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(sl);
+    FIELD_SWITCH(f, return ipa_virtual_scalars_run<F>((const Fe<F>*)p, (const Fe<F>*)w, (Fe<F>*)sl, (Fe<F>*)sr, m0, cur, (hipStream_t)stream));
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_ipa_update_weights_device(zk_field_t f, void* w, uint64_t m0, uint64_t bit, const void* u, void* stream) {
+    if (!w || !u || !aligned16(w)) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(w);
+    FIELD_SWITCH(f, {
+        Fe<F> uu;
+        host_load(uu, u);
+        return ipa_update_weights_run<F>((Fe<F>*)w, m0, bit, uu, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
 API int zk_expr_eval_device(zk_field_t f, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const void* consts,
                             uint32_t n_consts, uint32_t log_n, uint32_t rot_scale, void* out, void* stream) {
     if (!prog || !out || !aligned16(out) || (n_cols && !cols) || (n_consts && !consts)) return ZK_ERR_INVALID_ARG;

@@ -128,6 +128,25 @@ int vec_fold_run(Fe<F>* a, uint64_t half, const Fe<F>& c, hipStream_t st) {
     return ZK_OK;
 }
 
+template <class F>
+int ipa_virtual_scalars_run(const Fe<F>* p, const Fe<F>* W, Fe<F>* SL, Fe<F>* SR, uint64_t m0, uint64_t cur, hipStream_t st) {
+    if (m0 == 0 || cur < 2 || cur > m0 || (cur & (cur - 1)) != 0 || (m0 & (m0 - 1)) != 0) return ZK_ERR_INVALID_ARG;
+    uint64_t blocks = (m0 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ZK_LAUNCH((ipa_virtual_scalars_kernel<F>), (unsigned)blocks, 256, 0, st, p, W, SL, SR, m0, cur);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+template <class F>
+int ipa_update_weights_run(Fe<F>* W, uint64_t m0, uint64_t bit, const Fe<F>& u, hipStream_t st) {
+    if (m0 == 0 || bit == 0 || bit >= m0 || (bit & (bit - 1)) != 0) return ZK_ERR_INVALID_ARG;
+    uint64_t blocks = (m0 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ZK_LAUNCH((ipa_update_weights_kernel<F>), (unsigned)blocks, 256, 0, st, W, m0, bit, u);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
 // program / column table / constants are copied to the stream's scratch, then one grid-stride launch
 template <class F>
 int expr_eval_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const Fe<F>* consts,

@@ -230,6 +230,47 @@ __global__ void __launch_bounds__(256) vec_fold_kernel(Fe<F>* __restrict__ a, ui
     }
 }
 
+// ---- IPA without folding the generators ----
+// Folding G' costs one 255-bit scalar multiplication per surviving point and round (~260 point operations each, n of them
+// over the argument); an MSM costs ~16 bucket additions per point.  So the rounds are run over the ORIGINAL generators G0
+// (the resident SRS) instead: after the challenges u_1 .. u_r the folded generator is G'_i = sum_t W[i + t cur] G0[i + t cur]
+// (cur = n / 2^r, W[idx] = product of the u_a whose fold put idx in an upper half), hence
+//     L = <p'_hi, G'_lo> = MSM(G0, S_L),  S_L[idx] = p'[i + cur/2] W[idx] for i = idx mod cur < cur/2, else 0
+//     R = <p'_lo, G'_hi> = MSM(G0, S_R),  S_R[idx] = p'[i - cur/2] W[idx] for i >= cur/2,              else 0
+// two n-point MSMs with half of the scalars zero per round, one batched call; W is updated in place after each challenge.
+template <class F>
+__global__ void __launch_bounds__(256) ipa_virtual_scalars_kernel(const Fe<F>* __restrict__ p, const Fe<F>* __restrict__ W, Fe<F>* __restrict__ SL,
+                                                                  Fe<F>* __restrict__ SR, uint64_t m0, uint64_t cur) {
+    const uint64_t half = cur >> 1;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < m0; idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = idx & (cur - 1);
+        Fe<F> w = W[idx], z, x;
+        fe_zero(z);
+        if (i < half) {
+            x = p[i + half];
+            fe_mul(x, x, w);
+            SL[idx] = x;
+            SR[idx] = z;
+        } else {
+            x = p[i - half];
+            fe_mul(x, x, w);
+            SL[idx] = z;
+            SR[idx] = x;
+        }
+    }
+}
+// W[idx] *= u where idx has `bit` set (the upper half of the fold just made, bit = cur / 2)
+template <class F>
+__global__ void __launch_bounds__(256) ipa_update_weights_kernel(Fe<F>* __restrict__ W, uint64_t m0, uint64_t bit, Fe<F> u) {
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < m0; idx += (uint64_t)gridDim.x * blockDim.x) {
+        if (idx & bit) {
+            Fe<F> x = W[idx];
+            fe_mul(x, x, u);
+            W[idx] = x;
+        }
+    }
+}
+
 // ---- quotient numerator: a stack program evaluated at every row of the extended domain ----
 // (halo2_proofs 0.2 plonk/prover.rs: every gate polynomial, multiplied into the running sum by y, is an Expression over
 // advice / fixed / instance columns with rotations, evaluated on the extended coset; a rotation by r rows is a shift of

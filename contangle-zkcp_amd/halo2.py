@@ -19,7 +19,7 @@ from . import (Bases, _check, _np64, _ptr, base_limbs, curve_id, field_id, field
 
 PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo2_permutation_product_device",
                   "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
-                  "zk_expr_eval_device"]
+                  "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device"]
 
 
 def best_multiexp(coeffs, bases):
@@ -150,6 +150,8 @@ def _plib():
     lib.zk_inner_product_device.argtypes = [i32, vp, vp, u64, vp, vp]
     lib.zk_vec_fold_device.argtypes = [i32, vp, u64, vp, vp]
     lib.zk_ipa_fold_bases_device.argtypes = [i32, vp, u64, vp, vp]
+    lib.zk_ipa_virtual_scalars_device.argtypes = [i32, vp, vp, u64, u64, vp, vp, vp]
+    lib.zk_ipa_update_weights_device.argtypes = [i32, vp, u64, u64, vp, vp]
     lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     return lib
 
@@ -271,3 +273,51 @@ class IpaProver:
 
     def free(self):
         self.bases.free()
+
+
+class IpaProverVirtual:
+    """The same argument with the generators left alone: every round's L, R are MSMs over the ORIGINAL generators (a resident
+    `Bases`, e.g. the SRS itself) with scalars p'[i] W[idx]; W collects the challenges.  2 n-point MSMs (half of the scalars
+    zero) per round in one batched call, instead of a 255-bit scalar multiplication per surviving generator."""
+
+    def __init__(self, curve, d_p, d_b, bases, new_buffer, stream=0):
+        """new_buffer(shape) -> zero device buffer (torch on the GPU, numpy under the test emulator)"""
+        self.curve, self.field = curve_id(curve), scalar_field(curve)
+        self.p, self.b, self.bases, self.stream = d_p, d_b, bases, stream
+        self.m0 = self.n = int(d_p.shape[0])
+        assert self.n & (self.n - 1) == 0 and int(d_b.shape[0]) == self.n and bases.n >= self.n
+        self.S = new_buffer((2, self.m0, 4))
+        self.W = new_buffer((self.m0, 4))
+        one = _mont_limbs(1, field_modulus(self.field))
+        ones = np.tile(one, (self.m0, 1))
+        if isinstance(self.W, np.ndarray):
+            self.W[:] = ones
+        else:
+            import torch
+            self.W.copy_(torch.from_numpy(ones.view(np.int64)))
+
+    def round(self, sharded=False):
+        half = self.n // 2
+        _check(_plib().zk_ipa_virtual_scalars_device(self.field, _ptr(self.p), _ptr(self.W), self.m0, self.n, _ptr(self.S[0]), _ptr(self.S[1]),
+                                                     ctypes.c_void_p(self.stream)), "zk_ipa_virtual_scalars_device")
+        if sharded:
+            from . import dist as zkdist
+            L, R = zkdist.msm_batch_sharded(self.bases, self.S, montgomery=True, stream=self.stream)
+        else:
+            L, R = msm_batch(self.bases, self.S, montgomery=True, stream=self.stream)
+        vl = inner_product(self.field, self.p[half:self.n], self.b[:half], stream=self.stream)
+        vr = inner_product(self.field, self.p[:half], self.b[half:self.n], stream=self.stream)
+        return L, R, vl, vr
+
+    def fold(self, u):
+        half = self.n // 2
+        vec_fold(self.field, self.p, half, field_inverse(self.field, u), stream=self.stream)
+        vec_fold(self.field, self.b, half, u, stream=self.stream)
+        uu = _np64(u)
+        _check(_plib().zk_ipa_update_weights_device(self.field, _ptr(self.W), self.m0, half, _ptr(uu), ctypes.c_void_p(self.stream)),
+               "zk_ipa_update_weights_device")
+        self.n = half
+
+    def folded_generator(self):
+        """G' after the rounds so far are all done (n == 1): MSM(G0, W) -- what upstream's collapsed g_prime[0] is"""
+        return msm(self.bases, self.W, montgomery=True, stream=self.stream)

@@ -132,6 +132,17 @@ int zk_vec_fold_device(zk_field_t f, void *a_dev, uint64_t half, const void *c_m
  * 2 * half affine points (x, y) Montgomery on the device, u an element of the curve's scalar field (Montgomery, host) */
 int zk_ipa_fold_bases_device(zk_curve_t c, void *g_affine_dev, uint64_t half, const void *u_mont_host, void *hip_stream);
 
+/* The same rounds WITHOUT folding the generators (a fold is one ~255-bit scalar multiplication per surviving point and round;
+ * an MSM is ~16 bucket additions per point): with W[idx] the product of the challenges whose fold put idx in an upper half,
+ *   L = MSM(G0, S_L), R = MSM(G0, S_R) over the ORIGINAL m0 generators (the resident SRS handle, one zk_msm_batch_device call)
+ *   S_L[idx] = p'[i + cur/2] W[idx] for i = idx mod cur < cur/2 (else 0);  S_R[idx] = p'[i - cur/2] W[idx] for i >= cur/2 (else 0)
+ * zk_ipa_virtual_scalars_device fills S_L, S_R (m0 elements each); after the round's challenge u (and the p', b folds)
+ * zk_ipa_update_weights_device multiplies W[idx] by u where idx has bit cur/2 set.  W starts as all ones; the folded
+ * generator at the end is MSM(G0, W) (the prover does not need it). */
+int zk_ipa_virtual_scalars_device(zk_field_t f, const void *p_dev, const void *w_dev, uint64_t m0, uint64_t cur, void *sl_dev, void *sr_dev,
+                                  void *hip_stream);
+int zk_ipa_update_weights_device(zk_field_t f, void *w_dev, uint64_t m0, uint64_t bit, const void *u_mont_host, void *hip_stream);
+
 /* The quotient numerator: one stack program evaluated at every row of the extended domain (plonk/prover.rs: each gate's
  * Expression over advice / fixed / instance columns with rotations, folded with y).  A rotation by r rows is a shift of
  * r * rot_scale positions (rot_scale = 2^(extended_k - k)), cyclic.  The program must leave exactly one value; it is

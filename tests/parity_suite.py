@@ -686,6 +686,20 @@ def check_ipa(zk, cname, k, seed=13):
         ipa.fold(_monts(sf, [us[j]])[0])
     assert (to_host(zk, ipa.p)[0] == _monts(sf, [c_fin])[0]).all() and (to_host(zk, ipa.b)[0] == _monts(sf, [b_fin])[0]).all()
     assert (to_host(zk, ipa.g)[0] == aff(g_fin)).all()
+    ipa.free()
+    # the same argument without folding the generators: every L, R over the ORIGINAL generators, the challenges collected in W
+    srs = zk.Bases(cname, gens)
+    new_buffer = lambda shape: to_device(zk, np.zeros(shape, dtype=np.uint64))
+    vipa = zk.halo2.IpaProverVirtual(cname, to_device(zk, _monts(sf, pp)), to_device(zk, _monts(sf, b)), srs, new_buffer)
+    for j in range(k):
+        Lj, Rj, vl, vr = vipa.round()
+        eL, eR, evl, evr = rounds[j]
+        assert (zk.point_to_affine(cname, Lj) == aff(eL)).all() and (zk.point_to_affine(cname, Rj) == aff(eR)).all(), (cname, k, j, "virtual")
+        assert (vl == _monts(sf, [evl])[0]).all() and (vr == _monts(sf, [evr])[0]).all()
+        vipa.fold(_monts(sf, [us[j]])[0])
+    assert (to_host(zk, vipa.p)[0] == _monts(sf, [c_fin])[0]).all()
+    assert (zk.point_to_affine(cname, vipa.folded_generator()) == aff(g_fin)).all()
+    srs.free()
 
 
 def check_expression(zk, name, k, ext=2, seed=21):
