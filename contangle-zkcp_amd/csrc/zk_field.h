@@ -238,13 +238,17 @@ struct Fe2 {
 #else
 #define ZK_HD_CALL __attribute__((noinline))
 #endif
+// (Round 1 kept this callee on the portable product for the 12-limb field after a wrong result was attributed to the
+// generated inline-asm product running inside a non-inlined function whose operands arrive through the stack.  That
+// attribution did not hold up: tools/asm_callee_check.hip runs exactly that configuration -- and the 8-limb fields -- with all
+// lanes active, under a static divergent EXEC mask and inside a data-dependent loop, 3 x 65536 chained products per field,
+// and every result equals the portable product and the host's (profiles/r02_asm_callee_check.txt); the ISA of the callee
+// shows the 2 wait states between every v_mad_u64_u32 carry-out and its v_addc_co_u32 reader.  The asm product is used here
+// again; the BLS12-381 G2 parity tests on saturated limbs (zk_msm_opts.limb_bits = 32) cover it.)
 template <class P>
 ZK_HD_CALL Fe<P> fe_mul_call(Fe<P> a, Fe<P> b) {
     Fe<P> r;
-    if (P::N > 8)
-        fe_mul_portable(r, a, b);   // 12-limb operands arrive through the stack: keep this callee free of inline asm
-    else
-        fe_mul(r, a, b);
+    fe_mul(r, a, b);
     return r;
 }
 template <class P>
