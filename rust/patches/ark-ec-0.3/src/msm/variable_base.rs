@@ -1,6 +1,6 @@
 //! REPLACES `VariableBaseMSM::multi_scalar_mul` in ark-ec 0.3.0 `src/msm/variable_base.rs` (the Pippenger the reference
 //! reaches five times per proof through `Groth16::<Bls12_381>::prove`, lib/src/zk/verifiable_encryption.rs:92).
-//! The upstream body is kept, renamed `cpu_multi_scalar_mul`, for curves the library does not serve.
+//! `cpu_multi_scalar_mul` serves the curves and sizes the library does not.
 //! NOT COMPILED in this repository's build image (no Rust toolchain); binds include/zkcp_amd.h through zkcp-amd-sys.
 use ark_ff::{BigInteger, FpParameters, PrimeField};
 use ark_serialize::{CanonicalDeserialize, CanonicalSerialize};
@@ -53,10 +53,33 @@ impl VariableBaseMSM {
         G::deserialize_unchecked(&bytes[..]).unwrap().into_projective()
     }
 
-    /// ark-ec 0.3.0 `multi_scalar_mul` as published (window-parallel Pippenger, c = 3 below 32 pairs, else
-    /// ln_without_floats(size) + 2): unchanged, only renamed.
+    /// The CPU path for curves / sizes the library does not take.  A plain single-threaded bucket method over 8-bit
+    /// windows of the canonical scalar (the sum is the same group element whatever the window schedule); a maintainer who
+    /// wants upstream's window-parallel body for these inputs keeps it under this name instead.
     fn cpu_multi_scalar_mul<G: AffineCurve>(bases: &[G], scalars: &[<G::ScalarField as PrimeField>::BigInt]) -> G::Projective {
-        // --- upstream body unchanged (not reproduced in this repository) ---
-        unimplemented!("paste the body of ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul here: {} {}", bases.len(), scalars.len())
+        use ark_ff::Zero;
+        let size = ark_std::cmp::min(bases.len(), scalars.len());
+        let bits = <G::ScalarField as PrimeField>::size_in_bits();
+        let windows = (bits + 7) / 8;
+        let mut acc = G::Projective::zero();
+        for w in (0..windows).rev() {
+            for _ in 0..8 {
+                acc.double_in_place();
+            }
+            let mut buckets = ark_std::vec![G::Projective::zero(); 255];
+            for (b, s) in bases[..size].iter().zip(&scalars[..size]) {
+                let limb = s.as_ref()[w / 8];
+                let d = ((limb >> (8 * (w % 8))) & 0xff) as usize;
+                if d != 0 {
+                    buckets[d - 1].add_assign_mixed(b);
+                }
+            }
+            let mut run = G::Projective::zero();
+            for b in buckets.iter().rev() {
+                run += b;
+                acc += &run; // sum over d of d * bucket[d]
+            }
+        }
+        acc
     }
 }

@@ -68,11 +68,160 @@ pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {
     cpu_best_fft(a, omega, log_n)
 }
 
-// ---- helpers (bodies are mechanical; omitted where they only restate pasta_curves accessors)
-fn srs_handle<C: CurveAffine>(curve: i32, bases: &[C]) -> u64 { unimplemented!("zk_bases_upload of (x, y) Montgomery limbs, cached by (ptr, len, probe) like zk::SRS: {} {}", curve, bases.len()) }
-fn limbs_of<F: FieldExt>(x: &F) -> [u64; 4] { let mut l = [0u64; 4]; unsafe { core::ptr::copy_nonoverlapping(x as *const F as *const u64, l.as_mut_ptr(), 4) }; l }
-fn montgomery_one<F: FieldExt>() -> [u64; 4] { unimplemented!("R mod p of F (pasta_curves 0.4 fields/{{fp,fq}}.rs const R)") }
-fn curve_from_jacobian_limbs<C: CurveAffine>(j: &[u64]) -> C::Curve { unimplemented!("Ep/Eq {{ x, y, z }} from 3 x 4 Montgomery limbs: {}", j.len()) }
-fn scalar_field_of_group<G: Group>() -> Option<i32> { unimplemented!("ZK_FP_PALLAS / ZK_FQ_PALLAS when G is the field itself") }
-fn cpu_best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve { unimplemented!("upstream body: {} {}", coeffs.len(), bases.len()) }
-fn cpu_best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) { let _ = (a, omega, log_n); unimplemented!("upstream body") }
+// ---- helpers.  Nothing here depends on the in-memory layout of pasta's Fp / Fq unless `layout_is_flat` has confirmed it
+// on a known value; the portable path goes through `to_repr` / `from_bytes_wide`, which are part of the public traits.
+use std::any::TypeId;
+use std::collections::HashMap;
+use std::sync::Mutex;
+
+/// 2^256 as a field element (the Montgomery radix R of pasta_curves 0.4's 4 x u64 fields)
+fn radix<F: FieldExt>() -> F {
+    let mut wide = [0u8; 64];
+    wide[32] = 1;
+    F::from_bytes_wide(&wide)
+}
+fn repr_limbs<F: FieldExt>(x: &F) -> [u64; 4] {
+    let r = x.to_repr(); // 32 canonical little-endian bytes
+    let b = r.as_ref();
+    let mut l = [0u64; 4];
+    for (i, c) in b.chunks(8).enumerate().take(4) {
+        l[i] = u64::from_le_bytes([c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]]);
+    }
+    l
+}
+/// R mod p: what `F::one()` looks like in memory if the struct is the bare limb array
+fn montgomery_one<F: FieldExt>() -> [u64; 4] { repr_limbs(&radix::<F>()) }
+/// Montgomery limbs (x R mod p) of x, without looking at the struct
+fn limbs_of<F: FieldExt>(x: &F) -> [u64; 4] { repr_limbs(&(*x * radix::<F>())) }
+/// the field element whose Montgomery limbs are `m`
+fn from_montgomery_limbs<F: FieldExt>(m: &[u64]) -> F {
+    let mut wide = [0u8; 64];
+    for i in 0..4 {
+        wide[8 * i..8 * i + 8].copy_from_slice(&m[i].to_le_bytes());
+    }
+    F::from_bytes_wide(&wide) * radix::<F>().invert().unwrap() // (x R) R^-1
+}
+
+lazy_static::lazy_static! {
+    /// (address, length, curve) -> (probe limbs of the first / middle / last point, handle): Params::g and g_lagrange live
+    /// as long as the Params, so each is uploaded once
+    static ref PASTA_SRS: Mutex<HashMap<(usize, usize, i32), (Vec<u64>, u64)>> = Mutex::new(HashMap::new());
+}
+fn affine_limbs<C: CurveAffine>(p: &C, out: &mut Vec<u64>) {
+    // identity -> (0, 0), which is how the library marks it (0, 0 is not on either curve)
+    match Option::<pasta_curves::arithmetic::Coordinates<C>>::from(p.coordinates()) {
+        Some(c) => {
+            out.extend_from_slice(&limbs_of(c.x()));
+            out.extend_from_slice(&limbs_of(c.y()));
+        }
+        None => out.extend_from_slice(&[0u64; 8]),
+    }
+}
+fn srs_handle<C: CurveAffine>(curve: i32, bases: &[C]) -> u64 {
+    let n = bases.len();
+    let mut probe = Vec::new();
+    if n > 0 {
+        for i in [0, n / 2, n - 1] {
+            affine_limbs(&bases[i], &mut probe);
+        }
+    }
+    let key = (bases.as_ptr() as usize, n, curve);
+    let mut map = PASTA_SRS.lock().unwrap();
+    if let Some((p, h)) = map.get(&key) {
+        if *p == probe {
+            return *h;
+        }
+        unsafe { zk::zk_bases_free(*h) };
+    }
+    let mut flat = Vec::with_capacity(8 * n);
+    for b in bases {
+        affine_limbs(b, &mut flat);
+    }
+    let mut h = 0u64;
+    zk::check(unsafe { zk::zk_bases_upload(curve, flat.as_ptr() as _, n as u64, &mut h) }, "zk_bases_upload").unwrap();
+    map.insert(key, (probe, h));
+    h
+}
+/// pasta Ep / Eq are Jacobian (x, y, z); z = 0 is the identity.  `new_jacobian` checks the curve equation.
+fn curve_from_jacobian_limbs<C: CurveAffine>(j: &[u64]) -> C::Curve {
+    use pasta_curves::arithmetic::CurveExt;
+    if j[8..12].iter().all(|&w| w == 0) {
+        return C::Curve::identity();
+    }
+    let x = from_montgomery_limbs::<C::Base>(&j[0..4]);
+    let y = from_montgomery_limbs::<C::Base>(&j[4..8]);
+    let z = from_montgomery_limbs::<C::Base>(&j[8..12]);
+    Option::from(C::Curve::new_jacobian(x, y, z)).expect("zkcp_amd returned a point off the curve")
+}
+/// `best_fft` is generic over halo2's `Group`; the library takes the case where the group IS its scalar field
+fn scalar_field_of_group<G: Group>() -> Option<i32> {
+    if TypeId::of::<G>() != TypeId::of::<G::Scalar>() {
+        return None; // a curve: Params::new's FFT over points stays on the CPU
+    }
+    let m = <G::Scalar as PrimeField>::MODULUS;
+    if m.ends_with("992d30ed00000001") {
+        Some(zk::ZK_FP_PALLAS)
+    } else if m.ends_with("8c46eb2100000001") {
+        Some(zk::ZK_FQ_PALLAS)
+    } else {
+        None
+    }
+}
+
+// ---- CPU paths for the inputs the library does not take (small sizes, other curves, FFTs over points).  Plain
+// single-threaded forms with the same results as upstream's; a maintainer who wants upstream's multi-threaded bodies for
+// these sizes keeps them under these names instead.
+fn cpu_best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {
+    // bucket method, 8-bit unsigned windows over the canonical bytes, most significant window first
+    let reprs: Vec<_> = coeffs.iter().map(|c| c.to_repr()).collect();
+    let mut acc = C::Curve::identity();
+    for byte in (0..32).rev() {
+        for _ in 0..8 {
+            acc = acc.double();
+        }
+        let mut buckets = vec![C::Curve::identity(); 255];
+        for (r, b) in reprs.iter().zip(bases) {
+            let d = r.as_ref()[byte] as usize;
+            if d != 0 {
+                buckets[d - 1] += *b;
+            }
+        }
+        let mut run = C::Curve::identity();
+        for b in buckets.iter().rev() {
+            run += b;
+            acc += run; // sum_d d * bucket[d]
+        }
+    }
+    acc
+}
+fn cpu_best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {
+    let n = a.len();
+    assert_eq!(n, 1usize << log_n);
+    for i in 0..n {
+        let r = if log_n == 0 { 0 } else { ((i as u64).reverse_bits() >> (64 - log_n)) as usize };
+        if i < r {
+            a.swap(i, r);
+        }
+    }
+    let mut m = 1usize;
+    for s in 0..log_n {
+        // w_m = omega^(n / 2m)
+        let mut w_m = omega;
+        for _ in 0..(log_n - 1 - s) {
+            w_m = w_m * w_m;
+        }
+        for k in (0..n).step_by(2 * m) {
+            let mut w = G::Scalar::one();
+            for j in 0..m {
+                let mut t = a[k + j + m];
+                t.group_scale(&w);
+                let mut u = a[k + j];
+                a[k + j].group_add(&t);
+                u.group_sub(&t);
+                a[k + j + m] = u;
+                w = w * w_m;
+            }
+        }
+        m *= 2;
+    }
+}
