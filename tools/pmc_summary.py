@@ -73,7 +73,7 @@ def main():
         tj = {"kernel_src_sha16": sha, "workloads": {}}
     tj["note"] = ("per launch: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (KB units x 1024).  gfx950 FETCH_SIZE reports half the "
                   "bytes of wide coalesced streaming reads (MI355X_MICROARCH.md): doubled for ntt_pass_kernel (16-B-per-lane streams), taken at "
-                  "face value for msm_accumulate_kernel (random gathers of 80-byte records: uncalibrated pattern; Infinity-Cache hits are counted)")
+                  "face value for msm_accumulate_kernel (random gathers of 64-byte packed records: uncalibrated pattern; Infinity-Cache hits are counted)")
     entry = {}
     for want, corr in (("msm_accumulate_kernel", 1.0), ("ntt_pass_kernel", 2.0)):
         ks = [k for k in per if want in k and "big" not in k]
