@@ -82,9 +82,12 @@ def setup():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="NTTs and MSMs on one stream, MSMs one at a time (no overlap)")
     ap.add_argument("--workload", default="halo2", choices=["halo2", "column", "groth16"])
-    ap.add_argument("--ipa", default="virtual", choices=["virtual", "fold"],
-                    help="halo2 work-list, opening: 'virtual' runs every round's two MSMs over the resident SRS (default); 'fold' collapses the "
-                         "generator vector every round as upstream does (one scalar multiplication per surviving point)")
+    ap.add_argument("--ipa", default="collapse", choices=["collapse", "virtual", "fold"],
+                    help="halo2 work-list, opening: 'virtual' runs every round's two MSMs over the resident SRS; 'collapse' (default) does "
+                         "that for the first --ipa-collapse-after rounds, then materialises the surviving generators in one step "
+                         "(zk_ipa_collapse_device) and continues over them; 'fold' collapses the generator vector every round as upstream "
+                         "does (one scalar multiplication per surviving point)")
+    ap.add_argument("--ipa-collapse-after", type=int, default=8)
     ap.add_argument("--ntt-limbs", type=int, default=0, choices=[0, 32], help="0: lazy 29-bit limbs inside the NTT tiles (default); 32: saturated words (A/B)")
     args = ap.parse_args()
 
@@ -398,8 +401,9 @@ def bench_halo2(e):
         for j in range(k):
             ipa.round(sharded=e.world > 1)
             ipa.fold(us[j])
-        if a.ipa == "fold":
-            ipa.free()
+            if a.ipa == "collapse" and j + 1 == a.ipa_collapse_after and j + 1 < k:
+                ipa.collapse()
+        ipa.free()
         torch.cuda.synchronize()
         t5 = time.perf_counter()
         if timed_:
@@ -415,7 +419,9 @@ def bench_halo2(e):
                          "halo2 create_proof device work-list, 2^%d rows, the reference circuit's column layout (BASELINE configs[2]): advice 13 x (commit + l2c + c2e) ; "
                          "lookup 3 commits + product + 3 NTT chains ; permutation 3 products + 3 commits + 3 NTT chains ; quotient: random-poly commit, "
                          "%d-op expression over 27 extended columns, divide by Z_H, extended_to_coeff, 8 h-piece commits ; opening: %d-round IPA "
-                         "(2 MSMs + 2 inner products + 3 folds per round)" % (k, len(prog), k),
+                         "(2 MSMs + 2 inner products + 3 folds per round; generators %s)" % (
+                             k, len(prog), k, {"fold": "folded every round", "virtual": "never folded: every MSM over the SRS",
+                                               "collapse": "folded once, after round %d, by zk_ipa_collapse_device" % a.ipa_collapse_after}[a.ipa]),
                          {"rows_per_step": n, "msm_curve": curve, "msm_points": n, "msm_windows_done": 16, "msm_windows": 16,
                           "window_bits": 16, "columns": NCOL, "full_size_msms_per_step": n_msm, "ntt_2p%d_per_step" % k: 19, "ntt_2p%d_per_step" % ext: 20,
                           "streams": "one (serial)" if a.serial else "MSM batches on two library streams + NTT chains on a third",

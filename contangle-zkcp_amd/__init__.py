@@ -52,6 +52,7 @@ class MsmOpts(ctypes.Structure):
 
 
 MSM_FLAG_NO_HOT_HELP = 1
+MSM_FLAG_SLICE_REDUCE = 2
 
 
 class NttOpts(ctypes.Structure):
@@ -282,7 +283,7 @@ class Bases:
 
 
 def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len=0, big_threshold=0, waves_per_simd=0,
-             no_hot_help=False, base_offset=0):
+             no_hot_help=False, base_offset=0, slice_reduce=False):
     o = MsmOpts()
     o.window_bits = window_bits
     if windows is not None:
@@ -292,7 +293,7 @@ def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len
     o.slice_len = slice_len
     o.big_threshold = big_threshold
     o.waves_per_simd = waves_per_simd
-    o.flags = MSM_FLAG_NO_HOT_HELP if no_hot_help else 0
+    o.flags = (MSM_FLAG_NO_HOT_HELP if no_hot_help else 0) | (MSM_FLAG_SLICE_REDUCE if slice_reduce else 0)
     o.base_offset = base_offset
     return o
 

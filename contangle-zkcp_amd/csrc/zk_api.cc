@@ -101,6 +101,7 @@ MsmTuning tuning_from(const zk_msm_opts* o) {
     t.big_thresh = o->big_threshold > 0 ? (uint32_t)o->big_threshold : 0;
     t.waves = o->waves_per_simd;
     t.no_hot_help = (o->flags & ZK_MSM_FLAG_NO_HOT_HELP) != 0;
+    t.slice_reduce = (o->flags & ZK_MSM_FLAG_SLICE_REDUCE) != 0;
     t.base_offset = o->base_offset > 0 ? (uint64_t)o->base_offset : 0;
     return t;
 }
@@ -1086,6 +1087,27 @@ API int zk_ipa_fold_bases_device(zk_curve_t c, void* g_aff, uint64_t half, const
         fe_from_mont(u, u);
         return ipa_fold_bases_run<C>(dc, (Affine<C>*)g_aff, half, u, (hipStream_t)stream);
     });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_ipa_collapse_device(zk_curve_t c, uint64_t handle, const void* w, uint64_t m0, uint64_t cur, void* g_out, void* stream) {
+    if (!w || !g_out || !aligned16(w) || !aligned16(g_out)) return ZK_ERR_INVALID_ARG;
+    const BasesCopy* bc = nullptr;
+    uint64_t base_n = 0;
+    DeviceCtx* dcp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk0(g.mu);
+        ZK_TRY(require_init());
+        auto it = g.bases.find(handle);
+        if (it == g.bases.end()) return ZK_ERR_BAD_HANDLE;
+        if (it->second.curve != (int)c) return ZK_ERR_INVALID_ARG;
+        dcp = &device_of(g_out);
+        bc = &it->second.per_dev[dcp->index];
+        base_n = it->second.n;
+    }
+    DeviceCtx& dc = *dcp;
+    ZK_TRY(bind_device(dc));
+    std::lock_guard<std::mutex> lk(dc.mu);
+    CURVE_SWITCH(c, return ipa_collapse_run<C>(dc, *bc, base_n, (const Fe<typename C::Fr>*)w, m0, cur, (Affine<C>*)g_out, (hipStream_t)stream));
     return ZK_ERR_INVALID_ARG;
 }
 API int zk_ipa_virtual_scalars_device(zk_field_t f, const void* p, const void* w, uint64_t m0, uint64_t cur, void* sl, void* sr, void* stream) {

@@ -75,6 +75,7 @@ struct MsmTuning {
     int limb_bits = 0;        // 32 forces the saturated path
     int waves = 0;
     bool no_hot_help = false;
+    bool slice_reduce = false;   // the round-1 bucket reduction (slices + multiplier) instead of row / column sums
     uint64_t base_offset = 0;
 };
 
@@ -96,6 +97,8 @@ struct MsmJob {
     int (*finish)(MsmJob&, void* out_jac) = nullptr;
     int curve = 0, c = 0, w0 = 0, nw = 0;
     uint32_t per = 0;                 // partial sums per window
+    bool axes = false;                // row / column reduction: per window [row blocks | column blocks] x (weighted, plain)
+    uint32_t row_blocks = 0, col_blocks = 0, log_cols = 0, log_tl = 0;
     bool empty = true;                // nothing was launched (n == 0 or no windows): the result is the identity
     zk_msm_profile prof;
     double alg_bytes = 0;             // n x (scalar + affine point bytes) x share of the windows

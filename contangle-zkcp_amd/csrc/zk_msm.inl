@@ -39,13 +39,46 @@ int msm_finish_impl(MsmJob& job, void* out_jac) {
         const XYZZ<CK>* host = (const XYZZ<CK>*)job.host_partials;
         HostXYZZ<C> htotal, hp;
         to_host<C>(htotal, total);
+        auto load = [&](HostXYZZ<C>& r, size_t i) {
+            XYZZ<C> ps;
+            partial_to_std<C>(ps, host[i]);
+            to_host<C>(r, ps);
+        };
         for (int w = job.nw - 1; w >= 0; w--) {
             for (int k = 0; k < job.c; k++) xyzz_dbl(htotal);
-            for (uint32_t i = 0; i < job.per; i++) {
-                XYZZ<C> ps;
-                partial_to_std<C>(ps, host[(size_t)w * job.per + i]);
-                to_host<C>(hp, ps);
-                xyzz_add(htotal, hp);
+            if (!job.axes) {
+                for (uint32_t i = 0; i < job.per; i++) {
+                    load(hp, (size_t)w * job.per + i);
+                    xyzz_add(htotal, hp);
+                }
+                continue;
+            }
+            // row / column form: per window [row blocks | column blocks] x (W, S); axis total = sum_u W_u + TL sum_u u S_u,
+            // window total = 2^lc rows + columns
+            const size_t base = (size_t)w * job.per;
+            for (int axis = 0; axis < 2; axis++) {
+                const uint32_t nb = axis == 0 ? job.row_blocks : job.col_blocks;
+                const size_t b0 = base + 2 * (size_t)(axis == 0 ? 0 : job.row_blocks);
+                HostXYZZ<C> tot, run, acc;
+                load(tot, b0);
+                if (nb > 1) {
+                    XYZZ<C> inf;
+                    xyzz_set_inf(inf);
+                    to_host<C>(run, inf);
+                    to_host<C>(acc, inf);
+                    for (uint32_t u = nb - 1; u >= 1; u--) {
+                        load(hp, b0 + 2 * (size_t)u + 1);
+                        xyzz_add(run, hp);
+                        xyzz_add(acc, run);        // sum_u u S_u
+                        load(hp, b0 + 2 * (size_t)u);
+                        xyzz_add(tot, hp);
+                    }
+                    for (uint32_t k = 0; k < job.log_tl; k++) xyzz_dbl(acc);
+                    xyzz_add(tot, acc);
+                }
+                if (axis == 0)
+                    for (uint32_t k = 0; k < job.log_cols; k++) xyzz_dbl(tot);
+                xyzz_add(htotal, tot);
             }
         }
         for (int k = 0; k < job.c * job.w0; k++) xyzz_dbl(htotal);
@@ -152,18 +185,6 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
             ZK_TRY(ws_get(job.subacc, ((size_t)nbuckets << sh.split_log) * sizeof(XYZZ<CK>)));
             acc_out = (XYZZ<CK>*)job.subacc.p;
         }
-        // slice length of the bucket reduction: 64K lanes = one wave on every SIMD, which is what saturates the VALUs
-        // (the kernel is instruction-throughput-bound, not latency-bound); a rank of a window-sharded MSM owns few
-        // windows and gets shorter slices
-        uint32_t L = (uint32_t)(((uint64_t)nw_all * sh.nbk) >> 16);
-        if (L < 1) L = 1;
-        if (L > 8) L = 8;
-        if (tu.slice_len >= 1 && tu.slice_len <= 1024) L = tu.slice_len;
-        if (L > sh.nbk) L = sh.nbk;
-        const uint32_t spw = (sh.nbk + L - 1) / L;                  // slices per window
-        const uint32_t pbw = spw / 128 + 2;                          // second ping-pong buffer, points per window
-        ZK_TRY(ws_get(job.part_a, (size_t)spw * nw_all * sizeof(XYZZ<CK>)));
-        ZK_TRY(ws_get(job.part_b, (size_t)pbw * nw_all * sizeof(XYZZ<CK>)));
         // oversized-bucket lists: a bucket above big_thresh yields ceil(cnt / MSM_SEG) segments
         const size_t max_seg = ((size_t)n / MSM_SEG + (size_t)n / sh.big_thresh + 2) * nw_all;
         ZK_TRY(ws_get(job.queue, sizeof(MsmQueue) + max_seg * (sizeof(MsmSeg) + 8) + 64));
@@ -172,8 +193,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         MsmSeg* seg_list = (MsmSeg*)(q + 1);
         uint32_t* big_list = (uint32_t*)(seg_list + max_seg);
         XYZZ<CK>* seg_out = (XYZZ<CK>*)job.seg_out.p;
-        XYZZ<CK>* cur = (XYZZ<CK>*)job.part_a.p;
-        XYZZ<CK>* nxt = (XYZZ<CK>*)job.part_b.p;
+        XYZZ<CK>* cur = nullptr;   // the per-window partial sums that go to the host
         if (!job.have_events) {
             for (auto& e : job.ev) HIP_TRY(hipEventCreate(&e));
             job.have_events = true;
@@ -250,19 +270,73 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         ZK_LAUNCH((msm_combine_big_kernel<CK>), big_grid < 64 ? big_grid : 64u, tree_lanes<CK>(), 0, st, (const MsmQueue*)q,
                   (const uint32_t*)big_list, (const uint32_t*)counts, (const XYZZ<CK>*)seg_out, buckets);
         HIP_TRY(hipEventRecord(ev[4], st));
-        // ---- bucket reduction, then tree-sum the slices of each window until <= 8 remain
-        const uint32_t nslices = spw * (uint32_t)nw_all;
-        ZK_LAUNCH((msm_reduce_kernel<CK>), (nslices + 63) / 64, 64, 0, st, (const XYZZ<CK>*)buckets, cur, sh.nbk, L, spw, nslices);
-        uint32_t per = spw;
-        while (per > 8) {
-            const uint32_t E = per >= 1024 ? 4 : 1;
-            const uint32_t chunk = tree_lanes<CK>() * E;
-            const uint32_t per_out = (per + chunk - 1) / chunk;
-            ZK_LAUNCH((msm_sum_kernel<CK>), (unsigned)nw_all * per_out, tree_lanes<CK>(), 0, st, (const XYZZ<CK>*)cur, nxt, per, per_out, E);
-            per = per_out;
-            XYZZ<CK>* t = cur;
-            cur = nxt;
-            nxt = t;
+        uint32_t per = 0;
+        job.axes = !tu.slice_reduce;
+        if (job.axes) {
+            // ---- bucket reduction by row / column sums (zk_msm_kernels.h, MsmAxes)
+            constexpr uint32_t TL = tree_lanes<CK>();
+            MsmAxes A;
+            A.nbk = sh.nbk;
+            A.nw = (uint32_t)nw_all;
+            A.log_cols = (uint32_t)c / 2;                               // ceil((c - 1) / 2)
+            A.cols = 1u << A.log_cols;
+            A.rows = sh.nbk >> A.log_cols;
+            uint32_t K = 2;                                             // buckets per lane: <= ~2 waves per SIMD of lanes, at most 8
+            while (K < 8 && 2ull * A.nw * A.nbk / K > 131072) K <<= 1;
+            A.k_row = K < A.cols ? K : A.cols;
+            A.k_col = K < A.rows ? K : A.rows;
+            A.p_row = A.cols / A.k_row;
+            A.p_col = A.rows / A.k_col;
+            A.row_lanes = A.nw * A.rows * A.p_row;
+            A.col_lanes = A.nw * A.cols * A.p_col;
+            auto fold_blocks = [&](uint32_t nelem, uint32_t P) {
+                const uint32_t tw = P < 16 ? P : 16;
+                const uint32_t per_wg = TL / tw;
+                return (nelem + per_wg - 1) / per_wg;
+            };
+            const uint32_t fr = fold_blocks(A.nw * A.rows, A.p_row), fc = fold_blocks(A.nw * A.cols, A.p_col);
+            const uint32_t rb = (A.rows + TL - 1) / TL, cb = (A.cols + TL - 1) / TL;
+            per = 2 * (rb + cb);
+            ZK_TRY(ws_get(job.part_a, ((size_t)A.row_lanes + A.col_lanes) * sizeof(XYZZ<CK>)));
+            ZK_TRY(ws_get(job.part_b, ((size_t)A.nw * (A.rows + A.cols) + (size_t)A.nw * per) * sizeof(XYZZ<CK>)));
+            XYZZ<CK>* part = (XYZZ<CK>*)job.part_a.p;
+            XYZZ<CK>* elem = (XYZZ<CK>*)job.part_b.p;
+            cur = elem + (size_t)A.nw * (A.rows + A.cols);
+            ZK_LAUNCH((msm_axis_partials_kernel<CK>), (A.row_lanes + A.col_lanes + 63) / 64, 64, 0, st, (const XYZZ<CK>*)buckets, part, A);
+            ZK_LAUNCH((msm_axis_fold_kernel<CK>), fr + fc, TL, 0, st, (const XYZZ<CK>*)part, elem, A, fr);
+            ZK_LAUNCH((msm_axis_weighted_kernel<CK>), A.nw * (rb + cb), TL, 0, st, (const XYZZ<CK>*)elem, cur, A, rb, cb);
+            job.row_blocks = rb;
+            job.col_blocks = cb;
+            job.log_cols = A.log_cols;
+            job.log_tl = TL == 256 ? 8u : 7u;
+        } else {
+            // ---- slice form (ZK_MSM_FLAG_SLICE_REDUCE): running sums + windowed multiplier per slice, then tree-sum the
+            // slices of each window until <= 8 remain.  Slice length: 64K lanes = one wave on every SIMD; a rank of a
+            // window-sharded MSM owns few windows and gets shorter slices
+            uint32_t L = (uint32_t)(((uint64_t)nw_all * sh.nbk) >> 16);
+            if (L < 1) L = 1;
+            if (L > 8) L = 8;
+            if (tu.slice_len >= 1 && tu.slice_len <= 1024) L = tu.slice_len;
+            if (L > sh.nbk) L = sh.nbk;
+            const uint32_t spw = (sh.nbk + L - 1) / L;                  // slices per window
+            const uint32_t pbw = spw / 128 + 2;                          // second ping-pong buffer, points per window
+            ZK_TRY(ws_get(job.part_a, (size_t)spw * nw_all * sizeof(XYZZ<CK>)));
+            ZK_TRY(ws_get(job.part_b, (size_t)pbw * nw_all * sizeof(XYZZ<CK>)));
+            cur = (XYZZ<CK>*)job.part_a.p;
+            XYZZ<CK>* nxt = (XYZZ<CK>*)job.part_b.p;
+            const uint32_t nslices = spw * (uint32_t)nw_all;
+            ZK_LAUNCH((msm_reduce_kernel<CK>), (nslices + 63) / 64, 64, 0, st, (const XYZZ<CK>*)buckets, cur, sh.nbk, L, spw, nslices);
+            per = spw;
+            while (per > 8) {
+                const uint32_t E = per >= 1024 ? 4 : 1;
+                const uint32_t chunk = tree_lanes<CK>() * E;
+                const uint32_t per_out = (per + chunk - 1) / chunk;
+                ZK_LAUNCH((msm_sum_kernel<CK>), (unsigned)nw_all * per_out, tree_lanes<CK>(), 0, st, (const XYZZ<CK>*)cur, nxt, per, per_out, E);
+                per = per_out;
+                XYZZ<CK>* t = cur;
+                cur = nxt;
+                nxt = t;
+            }
         }
         HIP_TRY(hipEventRecord(ev[5], st));
         HIP_TRY(hipGetLastError());
@@ -466,6 +540,89 @@ int ipa_fold_bases_run(DeviceCtx& dc, Affine<C>* gens, uint64_t half, const Fe<t
     const uint64_t lanes = (half + FB_K - 1) / FB_K;
     ZK_LAUNCH((xyzz_batch_to_affine_kernel<C>), (unsigned)((lanes + 63) / 64), 64, 0, st, (const XYZZ<C>*)tmp, gens, (uint32_t)half);
     HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+// G'[i] = sum_{t < T} W_t G0[t cur + i] for i < cur (T = m0 / cur): what r = log2 T literal folds would have left in the
+// first `cur` generators (zk_msm_kernels.h, "Several IPA rounds of generator folding at once").  w_dev: the weight vector of
+// the fold-free rounds; only W[t cur] is read (the weights do not depend on i).
+template <class C>
+int ipa_collapse_run(DeviceCtx& dc, const BasesCopy& bc, uint64_t base_n, const Fe<typename C::Fr>* w_dev, uint64_t m0, uint64_t cur,
+                     Affine<C>* g_out, hipStream_t st) {
+    using Fr = typename C::Fr;
+    using CK = F29View<C>;
+    if (cur == 0 || m0 == 0 || (m0 & (m0 - 1)) || (cur & (cur - 1)) || cur > m0 || m0 > base_n) return ZK_ERR_INVALID_ARG;
+    if (m0 >= (1ull << 31) || m0 / cur > 4096 || !bc.dev29) return ZK_ERR_UNSUPPORTED;
+    const uint32_t T = (uint32_t)(m0 / cur), m = (uint32_t)cur;
+    if (T == 1) {
+        HIP_TRY(hipMemcpyAsync(g_out, bc.dev, (size_t)m * sizeof(Affine<C>), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return ZK_OK;
+    }
+    int lt = 0;
+    while ((1u << lt) < T) lt++;
+    int c = lt - 2;                      // ~8 entries per bucket
+    if (c < 2) c = 2;
+    if (c > 8) c = 8;
+    const uint32_t nbk = 1u << (c - 1);
+    const uint32_t nwin = (uint32_t)msm_windows<C>(c);
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    const size_t list_words = (size_t)nwin * nbk + 1 + (size_t)nwin * T;
+    ZK_TRY(ws_get(ss->poly_a, (size_t)T * sizeof(Fe<Fr>) + list_words * 4 + 64));
+    ZK_TRY(ws_get(ss->poly_b, (size_t)nwin * m * sizeof(XYZZ<CK>)));
+    ZK_TRY(ws_get(ss->fb_tmp, (size_t)m * sizeof(XYZZ<C>)));
+    Fe<Fr>* d_w = (Fe<Fr>*)ss->poly_a.p;
+    uint32_t* d_off = (uint32_t*)(d_w + T);
+    uint32_t* d_ent = d_off + (size_t)nwin * nbk + 1;
+    XYZZ<CK>* part = (XYZZ<CK>*)ss->poly_b.p;
+    XYZZ<C>* tmp = (XYZZ<C>*)ss->fb_tmp.p;
+    ZK_LAUNCH((ipa_gather_weights_kernel<C>), (T + 255) / 256, 256, 0, st, w_dev, (uint64_t)m, T, d_w);
+    std::vector<Fe<Fr>> wt(T);
+    HIP_TRY(hipMemcpyAsync(wt.data(), d_w, (size_t)T * sizeof(Fe<Fr>), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // signed c-bit digits of every weight (the carry method of msm_digits_kernel), then the bucket lists of every window
+    auto bits = [&](const Fe<Fr>& x, int start) -> uint32_t {
+        uint64_t v = 0;
+        const int idx = start >> 5, sh = start & 31;
+        if (idx < Fr::N) v = x.v[idx];
+        if (idx + 1 < Fr::N) v |= (uint64_t)x.v[idx + 1] << 32;
+        return (uint32_t)(v >> sh) & ((1u << c) - 1);
+    };
+    std::vector<int32_t> dig((size_t)nwin * T);
+    std::vector<uint32_t> off((size_t)nwin * nbk + 1, 0), ent((size_t)nwin * T);
+    for (uint32_t t = 0; t < T; t++) {
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < nwin; w++) {
+            const uint32_t raw = bits(wt[t], (int)(w * c)) + carry;
+            const bool neg = raw > nbk;
+            const uint32_t mag = neg ? (1u << c) - raw : raw;
+            carry = neg ? 1u : 0u;
+            dig[(size_t)w * T + t] = neg ? -(int32_t)mag : (int32_t)mag;
+            if (mag) off[(size_t)w * nbk + (mag - 1) + 1]++;
+        }
+    }
+    for (size_t k = 1; k < off.size(); k++) off[k] += off[k - 1];
+    {
+        std::vector<uint32_t> pos(off.begin(), off.end() - 1);
+        for (uint32_t w = 0; w < nwin; w++)
+            for (uint32_t t = 0; t < T; t++) {
+                const int32_t d = dig[(size_t)w * T + t];
+                if (d == 0) continue;
+                const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+                ent[pos[(size_t)w * nbk + (mag - 1)]++] = t | (d < 0 ? 0x80000000u : 0u);
+            }
+    }
+    HIP_TRY(hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_ent, ent.data(), ent.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // the host vectors go out of scope below
+    const uint64_t lanes = (uint64_t)nwin * m;
+    ZK_LAUNCH((ipa_collapse_window_kernel<CK>), (unsigned)((lanes + 63) / 64), 64, 0, st, (const StoredAffine<CK>*)bc.dev29,
+              (const uint32_t*)d_off, (const uint32_t*)d_ent, part, m, nbk, nwin);
+    ZK_LAUNCH((ipa_collapse_horner_kernel<C>), (m + 63) / 64, 64, 0, st, (const XYZZ<CK>*)part, tmp, m, (uint32_t)c, nwin);
+    const uint64_t nl = ((uint64_t)m + FB_K - 1) / FB_K;
+    ZK_LAUNCH((xyzz_batch_to_affine_kernel<C>), (unsigned)((nl + 63) / 64), 64, 0, st, (const XYZZ<C>*)tmp, g_out, m);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));   // g_out is complete on return: the caller adopts it as a bases handle next (any stream)
     return ZK_OK;
 }
 }  // namespace zk

@@ -73,6 +73,31 @@ __device__ __forceinline__ uint32_t digit_mag(uint32_t code, bool& neg) {
     return neg ? 0x10000u - code : code;
 }
 
+// atomicAdd(&ctr[key], 1) for every lane with `valid`, returning the value before the lane's increment -- but the lanes of
+// the wave that share the first valid lane's key are served by ONE atomic (ballot + popcount).  For a skewed witness most
+// entries of the hot region carry the same bucket (the unit scalars of a Groth16 assignment): same-address LDS atomics
+// serialise lane by lane, this does not.  Every lane of the wave must call it (wave-uniform trip counts).
+#ifdef ZK_EMU
+#define ZK_READLANE(v, l) __shfl((v), (l))
+#else
+#define ZK_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (l)))   // `l` is wave-uniform here: no LDS round trip
+#endif
+__device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* ctr, uint32_t key, bool valid) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0) return 0;
+    const int leader = __ffsll((unsigned long long)vm) - 1;
+    const uint32_t hot = ZK_READLANE(key, leader);
+    const bool match = valid && key == hot;
+    const uint64_t mm = __ballot(match);
+    uint32_t base = 0;
+    if (lane == (uint32_t)leader) base = atomicAdd(&ctr[hot], (uint32_t)__popcll((unsigned long long)mm));
+    base = ZK_READLANE(base, leader);
+    if (match) return base + (uint32_t)__popcll((unsigned long long)(mm & ((1ull << lane) - 1)));
+    if (valid) return atomicAdd(&ctr[key], 1u);
+    return 0;
+}
+
 // grid = ceil(n / MSM_SBLK).  Writes the digit codes window-major (digits[w * n + i]) and counts this block's non-zero
 // digits per region: blockcnt[region * nblocks + block], region = window * nranges + range
 template <class C>
@@ -84,11 +109,19 @@ __global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::F
     const uint32_t rb_log = 31u - (uint32_t)__clz(sh.rb);
     for (uint32_t j = threadIdx.x; j < nreg; j += blockDim.x) cnt[j] = 0;
     __syncthreads();
+    // few ranges per window (small c: the later IPA rounds, small keys): the lanes of a wave mostly hit the SAME counter, and
+    // same-address LDS atomics serialise lane by lane (0.12 ms for 2^12 scalars x 32 windows in one workgroup) -- one
+    // aggregated atomic per wave and counter instead.  Trip counts are wave-uniform: no lane leaves the loops early.
+    const bool agg = sh.nranges <= 8;
     for (uint32_t k = threadIdx.x; k < MSM_SBLK; k += blockDim.x) {
         const uint32_t i = blockIdx.x * MSM_SBLK + k;
-        if (i >= sh.n) break;
-        Fe<Fr> x = scalars[i];
-        if (sh.mont) fe_from_mont(x, x);
+        const bool valid = i < sh.n;
+        Fe<Fr> x;
+        fe_zero(x);
+        if (valid) {
+            x = scalars[i];
+            if (sh.mont) fe_from_mont(x, x);
+        }
         uint32_t carry = 0;
         for (int w = 0; w < sh.w0 + sh.nw; w++) {
             const uint32_t raw = bits_at<Fr::N>(x.v, w * sh.c, sh.c) + carry;
@@ -97,8 +130,12 @@ __global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::F
             carry = neg ? 1u : 0u;
             if (w >= sh.w0) {
                 const uint32_t wl = (uint32_t)(w - sh.w0);
-                digits[(uint64_t)wl * sh.n + i] = (uint16_t)(neg ? 0x10000u - mag : mag);
-                if (mag != 0) atomicAdd(&cnt[wl * sh.nranges + ((mag - 1) >> rb_log)], 1u);
+                if (valid) digits[(uint64_t)wl * sh.n + i] = (uint16_t)(neg ? 0x10000u - mag : mag);
+                const uint32_t key = wl * sh.nranges + (mag ? (mag - 1) >> rb_log : 0u);
+                if (agg)
+                    wave_agg_inc(cnt, key, mag != 0);
+                else if (mag != 0)
+                    atomicAdd(&cnt[key], 1u);
             }
         }
     }
@@ -223,31 +260,6 @@ __global__ void __launch_bounds__(1024) msm_stage_kernel(const uint16_t* __restr
 }
 
 constexpr uint32_t MSM_HOT_UNROLL = 8;   // entries per lane and iteration in the hot-region loops of the sort kernel
-
-// atomicAdd(&ctr[key], 1) for every lane with `valid`, returning the value before the lane's increment -- but the lanes of
-// the wave that share the first valid lane's key are served by ONE atomic (ballot + popcount).  For a skewed witness most
-// entries of the hot region carry the same bucket (the unit scalars of a Groth16 assignment): same-address LDS atomics
-// serialise lane by lane, this does not.  Every lane of the wave must call it (wave-uniform trip counts).
-#ifdef ZK_EMU
-#define ZK_READLANE(v, l) __shfl((v), (l))
-#else
-#define ZK_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (l)))   // `l` is wave-uniform here: no LDS round trip
-#endif
-__device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* ctr, uint32_t key, bool valid) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t vm = __ballot(valid);
-    if (vm == 0) return 0;
-    const int leader = __ffsll((unsigned long long)vm) - 1;
-    const uint32_t hot = ZK_READLANE(key, leader);
-    const bool match = valid && key == hot;
-    const uint64_t mm = __ballot(match);
-    uint32_t base = 0;
-    if (lane == (uint32_t)leader) base = atomicAdd(&ctr[hot], (uint32_t)__popcll((unsigned long long)mm));
-    base = ZK_READLANE(base, leader);
-    if (match) return base + (uint32_t)__popcll((unsigned long long)(mm & ((1ull << lane) - 1)));
-    if (valid) return atomicAdd(&ctr[key], 1u);
-    return 0;
-}
 
 // ---- hot regions (far above the mean: a skewed witness) are histogrammed and scattered by many workgroups ----
 constexpr uint32_t MSM_HOT_MAX = 8;       // hot regions served this way (the rest stay with their own sort workgroup)
@@ -933,6 +945,164 @@ __global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<C>* __restrict_
     if (tid == 0) out[(uint64_t)s * per_out + o] = acc;
 }
 
+// ------------------------------------------------------------------------------------------
+// Bucket reduction by row and column sums (the default; the slice kernels above stay behind ZK_MSM_FLAG_SLICE_REDUCE for A/B).
+// The slice form spends 24 of its 40 steps per lane multiplying a slice total by its offset: 2.6 M additions for the 2^19
+// buckets of a 2^20-point MSM, where the sum itself needs 2 per bucket.  Here a window's nbk = R x C buckets are a matrix,
+// bucket b = hi C + lo (weight b + 1):
+//     sum_b (b + 1) B_b  =  C * sum_hi hi * Row_hi  +  sum_lo (lo + 1) * Col_lo          Row_hi = sum_lo B, Col_lo = sum_hi B
+// so every bucket is added exactly twice, with no multiplications, and what remains are two weighted sums over R and C
+// (<= 256) points per window, which a workgroup does as a suffix scan followed by a tree (sum_k (k + 1) x_k = sum of all
+// suffix sums).
+//   msm_axis_partials_kernel   lane = K buckets of one row (stride C / K: neighbouring lanes read neighbouring buckets) or of
+//                              one column -> a partial sum                                              K - 1 additions
+//   msm_axis_fold_kernel       TW lanes per row / column: its partials -> Row_hi / Col_lo               log2 steps in LDS
+//   msm_axis_weighted_kernel   workgroup per (window, axis, block of TL elements): W = sum (t + 1) x_t and S = sum x_t
+//   host                       axis total = sum_u W_u + TL * sum_u u S_u ; window = 2^lc * rows + columns ; Horner
+// Each kernel has ONE addition site (instruction cache: see msm_reduce_kernel).
+// ------------------------------------------------------------------------------------------
+struct MsmAxes {
+    uint32_t nbk;        // buckets per window = rows * cols
+    uint32_t nw;         // windows
+    uint32_t log_cols;   // C = 2^log_cols, R = nbk / C  (R <= C)
+    uint32_t k_row, k_col;   // buckets per lane in the partials kernel (powers of two, k_row <= C, k_col <= R)
+    // derived
+    uint32_t rows, cols, p_row, p_col;   // partials per row = C / k_row, per column = R / k_col
+    uint32_t row_lanes, col_lanes;       // nw * rows * p_row, nw * cols * p_col
+};
+
+template <class C>
+__global__ void __launch_bounds__(64) msm_axis_partials_kernel(const XYZZ<C>* __restrict__ buckets, XYZZ<C>* __restrict__ part, MsmAxes A) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt >= A.row_lanes + A.col_lanes) return;
+    uint64_t addr;
+    uint32_t stride, count, dst;
+    if (gt < A.row_lanes) {            // (window, row, k): buckets hi C + k + j p_row
+        const uint32_t k = gt % A.p_row, hi = (gt / A.p_row) % A.rows, w = gt / (A.p_row * A.rows);
+        addr = (uint64_t)w * A.nbk + (uint64_t)hi * A.cols + k;
+        stride = A.p_row;
+        count = A.k_row;
+        dst = gt;                      // [window][row][k]
+    } else {                           // (window, hc, column): buckets (hc k_col + j) C + lo ; neighbouring lanes = neighbouring columns
+        const uint32_t gl = gt - A.row_lanes;
+        const uint32_t lo = gl % A.cols, hc = (gl / A.cols) % A.p_col, w = gl / (A.cols * A.p_col);
+        addr = (uint64_t)w * A.nbk + (uint64_t)hc * A.k_col * A.cols + lo;
+        stride = A.cols;
+        count = A.k_col;
+        dst = A.row_lanes + (w * A.cols + lo) * A.p_col + hc;   // [window][column][hc]
+    }
+    XYZZ<C> acc = buckets[addr];
+    XYZZ<C> nxt;
+    xyzz_set_inf(nxt);
+    if (count > 1) nxt = buckets[addr + stride];
+#pragma unroll 1
+    for (uint32_t j = 1; j < count; j++) {
+        const XYZZ<C> b = nxt;
+        if (j + 1 < count) nxt = buckets[addr + (uint64_t)(j + 1) * stride];   // the load overlaps the addition
+        xyzz_add(acc, b);
+    }
+    part[dst] = acc;
+}
+
+// elem[e] = sum of part[e P .. e P + P): the rows (P = p_row) then the columns (P = p_col) of every window.  TW = min(P, 16)
+// lanes per element; a lane adds P / TW partials (stride TW), then an LDS tree over the TW lanes.
+template <class C>
+__global__ void __launch_bounds__(256) msm_axis_fold_kernel(const XYZZ<C>* __restrict__ part, XYZZ<C>* __restrict__ elem, MsmAxes A,
+                                                            uint32_t row_blocks) {
+    constexpr uint32_t TL = tree_lanes<C>();
+    __shared__ XYZZ<C> sh[TL];
+    const uint32_t tid = threadIdx.x;
+    const bool is_row = blockIdx.x < row_blocks;
+    const uint32_t P = is_row ? A.p_row : A.p_col;
+    const uint32_t nelem = is_row ? A.nw * A.rows : A.nw * A.cols;
+    const uint32_t TW = P < 16 ? P : 16;                  // lanes per element (power of two)
+    const uint32_t per_wg = TL / TW;
+    const uint32_t e = (is_row ? blockIdx.x : blockIdx.x - row_blocks) * per_wg + tid / TW;
+    const uint32_t sub = tid % TW;
+    const bool live = e < nelem;
+    const XYZZ<C>* src = part + (is_row ? 0u : A.row_lanes) + (uint64_t)e * P;
+    const uint32_t serial = P / TW;
+    uint32_t nlev = 0;
+    for (uint32_t d = TW >> 1; d > 0; d >>= 1) nlev++;
+    XYZZ<C> acc, nxt;
+    xyzz_set_inf(acc);
+    xyzz_set_inf(nxt);
+    if (live) nxt = src[sub];
+#pragma unroll 1
+    for (uint32_t k = 0; k < serial + nlev; k++) {
+        XYZZ<C> b = nxt;
+        bool on;
+        if (k < serial) {
+            on = live;
+            if (on && k + 1 < serial) nxt = src[sub + (k + 1) * TW];
+        } else {
+            const uint32_t d = TW >> (k - serial + 1);
+            on = sub < d;
+            if (on) b = sh[tid + d];
+        }
+        if (on) xyzz_add(acc, b);
+        if (k + 1 >= serial) {
+            __syncthreads();            // every read of this level is done
+            sh[tid] = acc;
+            __syncthreads();
+        }
+    }
+    if (live && sub == 0) elem[(is_row ? 0u : A.nw * A.rows) + e] = acc;
+}
+
+// One workgroup per (window, axis, block u of TL elements).  x_t = element u TL + t + shift of the axis (shift = 1 for the rows:
+// Row_hi has weight hi, so Row_0 drops out and x_t = Row_{t + 1}; 0 for the columns), infinity beyond the axis.
+//   out[2 i]     = sum_t (t + 1) x_t         (suffix scan, then a tree over the suffix sums)
+//   out[2 i + 1] = sum_t x_t                 (the first suffix sum)
+template <class C>
+__global__ void __launch_bounds__(256) msm_axis_weighted_kernel(const XYZZ<C>* __restrict__ elem, XYZZ<C>* __restrict__ out, MsmAxes A,
+                                                                uint32_t row_blocks, uint32_t col_blocks) {
+    constexpr uint32_t TL = tree_lanes<C>();
+    __shared__ XYZZ<C> sh[TL];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per_w = row_blocks + col_blocks;
+    const uint32_t w = blockIdx.x / per_w, bi = blockIdx.x % per_w;
+    const bool is_row = bi < row_blocks;
+    const uint32_t u = is_row ? bi : bi - row_blocks;
+    const uint32_t len = is_row ? A.rows : A.cols;
+    const XYZZ<C>* src = elem + (is_row ? (uint64_t)w * A.rows : (uint64_t)A.nw * A.rows + (uint64_t)w * A.cols);
+    const uint32_t g = u * TL + tid + (is_row ? 1u : 0u);
+    XYZZ<C> acc, total;
+    xyzz_set_inf(acc);
+    xyzz_set_inf(total);
+    if (g < len) acc = src[g];
+    uint32_t E = len - u * TL < TL ? len - u * TL : TL;    // elements of this block (a power of two)
+    uint32_t logE = 0;
+    while ((1u << logE) < E) logE++;
+    sh[tid] = acc;
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t k = 0; k < 2 * logE; k++) {
+        uint32_t off;
+        bool on;
+        if (k < logE) {                 // suffix scan: x_t += x_{t + 2^k}
+            off = 1u << k;
+            on = tid + off < E;
+        } else {                        // tree over the suffix sums
+            off = E >> (k - logE + 1);
+            on = tid < off;
+        }
+        if (k == logE) total = acc;     // lane 0: the plain sum
+        XYZZ<C> b;
+        xyzz_set_inf(b);
+        if (on) b = sh[tid + off];
+        __syncthreads();
+        if (on) xyzz_add(acc, b);
+        sh[tid] = acc;
+        __syncthreads();
+    }
+    if (logE == 0) total = acc;
+    if (tid == 0) {
+        out[2 * (uint64_t)blockIdx.x] = acc;
+        out[2 * (uint64_t)blockIdx.x + 1] = total;
+    }
+}
+
 template <class C>
 __device__ __forceinline__ void pack_base(Affine<C>& r, const Affine<C29<C>>& q) {
     fe29_pack(r.x, q.x);
@@ -1023,6 +1193,86 @@ __global__ void __launch_bounds__(64) ipa_fold_bases_kernel(const Affine<C>* __r
     XYZZ<C> r;
     xyzz29_to_std<C>(r, acc);
     tmp[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Several IPA rounds of generator folding at once.  After r rounds of the fold-free form (zk_ipa_virtual_scalars_device) the
+// generators upstream would hold are
+//     G'[i] = sum_{t < T} W_t G0[t m + i]        i < m = m0 / T, T = 2^r, W_t = the product of the challenges that t's bits select
+// -- m multi-scalar multiplications over T points each that all use the SAME T scalars.  So the digit decomposition and the
+// bucket lists of the T scalars are made once, on the host (T <= 2^12), and the device work is perfectly regular: lane
+// (i, window) walks the window's buckets from the top, sums each bucket's points G0[t m + i] (neighbouring lanes read
+// neighbouring points), and keeps the two running sums of the bucket method; a second kernel does the Horner over the
+// windows of every output.  ~(255 / c) additions per original generator instead of the ~260 point operations per survivor
+// of every literal fold, and no latency-bound small rounds in between.
+// ------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(256) ipa_gather_weights_kernel(const Fe<typename C::Fr>* __restrict__ w, uint64_t stride, uint32_t T,
+                                                                 Fe<typename C::Fr>* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    Fe<typename C::Fr> x = w[(uint64_t)t * stride];
+    fe_from_mont(x, x);
+    out[t] = x;
+}
+
+// list_off[w nbk + b] .. list_off[w nbk + b + 1]: the entries (t | sign << 31) whose digit in window w has magnitude b + 1
+template <class CK>
+__global__ void __launch_bounds__(64) ipa_collapse_window_kernel(const StoredAffine<CK>* __restrict__ bases, const uint32_t* __restrict__ list_off,
+                                                                 const uint32_t* __restrict__ list_ent, XYZZ<CK>* __restrict__ out, uint32_t m,
+                                                                 uint32_t nbk, uint32_t nwin) {
+    const uint64_t gt = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = (uint32_t)(gt % m), w = (uint32_t)(gt / m);
+    if (w >= nwin) return;
+    XYZZ<CK> run, acc;
+    xyzz_set_inf(run);
+    xyzz_set_inf(acc);
+    const uint32_t* off = list_off + (uint64_t)w * nbk;
+#pragma unroll 1
+    for (uint32_t b = nbk; b-- > 0;) {
+        XYZZ<CK> bsum;
+        xyzz_set_inf(bsum);
+        const uint32_t e1 = off[b + 1];
+#pragma unroll 1
+        for (uint32_t k = off[b]; k < e1; k++) {
+            const uint32_t e = list_ent[k];
+            Affine<CK> p;
+            load_base(p, bases, (e & 0x7fffffffu) * m + i);
+            aff_neg_if(p, (e >> 31) != 0);
+            xyzz_add_mixed(bsum, p);
+        }
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {          // run += bsum ; acc += run   (one addition site)
+            XYZZ<CK> X = s ? acc : run;
+            const XYZZ<CK> Y = s ? run : bsum;
+            xyzz_add(X, Y);
+            if (s)
+                acc = X;
+            else
+                run = X;
+        }
+    }
+    out[(uint64_t)w * m + i] = acc;
+}
+
+// out[i] = sum_w 2^(c w) part[w m + i]  (Horner from the top window), as a saturated-limb XYZZ point for the batched normalisation
+template <class C>
+__global__ void __launch_bounds__(64) ipa_collapse_horner_kernel(const XYZZ<F29View<C>>* __restrict__ part, XYZZ<C>* __restrict__ out, uint32_t m,
+                                                                 uint32_t c, uint32_t nwin) {
+    using CK = F29View<C>;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    XYZZ<CK> acc = part[(uint64_t)(nwin - 1) * m + i];
+#pragma unroll 1
+    for (uint32_t w = nwin - 1; w-- > 0;) {
+#pragma unroll 1
+        for (uint32_t k = 0; k < c; k++) xyzz_dbl(acc);
+        const XYZZ<CK> p = part[(uint64_t)w * m + i];
+        xyzz_add(acc, p);
+    }
+    XYZZ<C> r;
+    xyzz29_to_std<C>(r, acc);
+    out[i] = r;
 }
 
 // ------------------------------------------------------------------------------------------

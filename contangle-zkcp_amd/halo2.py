@@ -19,7 +19,7 @@ from . import (Bases, _check, _np64, _ptr, base_limbs, curve_id, field_id, field
 
 PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo2_permutation_product_device",
                   "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
-                  "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device"]
+                  "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device"]
 
 
 def best_multiexp(coeffs, bases):
@@ -152,6 +152,7 @@ def _plib():
     lib.zk_ipa_fold_bases_device.argtypes = [i32, vp, u64, vp, vp]
     lib.zk_ipa_virtual_scalars_device.argtypes = [i32, vp, vp, u64, u64, vp, vp, vp]
     lib.zk_ipa_update_weights_device.argtypes = [i32, vp, u64, u64, vp, vp]
+    lib.zk_ipa_collapse_device.argtypes = [i32, u64, vp, u64, u64, vp, vp]
     lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     return lib
 
@@ -278,16 +279,26 @@ class IpaProver:
 class IpaProverVirtual:
     """The same argument with the generators left alone: every round's L, R are MSMs over the ORIGINAL generators (a resident
     `Bases`, e.g. the SRS itself) with scalars p'[i] W[idx]; W collects the challenges.  2 n-point MSMs (half of the scalars
-    zero) per round in one batched call, instead of a 255-bit scalar multiplication per surviving generator."""
+    zero) per round in one batched call, instead of a 255-bit scalar multiplication per surviving generator.
+
+    `collapse()` materialises the generators that the rounds so far would have left (zk_ipa_collapse_device: the
+    surviving points as multi-scalar multiplications that share their scalars) and continues over them: the first rounds
+    cost one full-size MSM each, the remaining ones only what their own size costs."""
 
     def __init__(self, curve, d_p, d_b, bases, new_buffer, stream=0):
         """new_buffer(shape) -> zero device buffer (torch on the GPU, numpy under the test emulator)"""
         self.curve, self.field = curve_id(curve), scalar_field(curve)
         self.p, self.b, self.bases, self.stream = d_p, d_b, bases, stream
+        self.new_buffer = new_buffer
         self.m0 = self.n = int(d_p.shape[0])
         assert self.n & (self.n - 1) == 0 and int(d_b.shape[0]) == self.n and bases.n >= self.n
-        self.S = new_buffer((2, self.m0, 4))
-        self.W = new_buffer((self.m0, 4))
+        self._own_bases = None
+        self._g = None
+        self._fresh_weights()
+
+    def _fresh_weights(self):
+        self.S = self.new_buffer((2, self.m0, 4))
+        self.W = self.new_buffer((self.m0, 4))
         one = _mont_limbs(1, field_modulus(self.field))
         ones = np.tile(one, (self.m0, 1))
         if isinstance(self.W, np.ndarray):
@@ -317,6 +328,25 @@ class IpaProverVirtual:
         _check(_plib().zk_ipa_update_weights_device(self.field, _ptr(self.W), self.m0, half, _ptr(uu), ctypes.c_void_p(self.stream)),
                "zk_ipa_update_weights_device")
         self.n = half
+
+    def collapse(self):
+        """G' of the rounds done so far, as a device buffer [n, 2 * limbs] of affine points; the later rounds run over it"""
+        nl = _plib().zk_curve_base_limbs64(self.curve)
+        g = self.new_buffer((self.n, 2 * nl))
+        _check(_plib().zk_ipa_collapse_device(self.curve, self.bases.handle, _ptr(self.W), self.m0, self.n, _ptr(g), ctypes.c_void_p(self.stream)),
+               "zk_ipa_collapse_device")
+        if self._own_bases is not None:
+            self._own_bases.free()
+        self._g = g                                   # adopted, not copied: kept alive here
+        self._own_bases = self.bases = Bases(self.curve, device_tensor=g, n=self.n)
+        self.m0 = self.n
+        self._fresh_weights()
+        return g
+
+    def free(self):
+        if self._own_bases is not None:
+            self._own_bases.free()
+            self._own_bases = None
 
     def folded_generator(self):
         """G' after the rounds so far are all done (n == 1): MSM(G0, W) -- what upstream's collapsed g_prime[0] is"""

@@ -79,7 +79,7 @@ typedef struct {
     int window_end;     /*   decomposition, already weighted by 2^(c*w); 0,0 = all windows           */
     int limb_bits;      /* bucket arithmetic: 0 = default (lazy 29/28-bit limbs), 32 = saturated 32-bit words (A/B, tests) */
     int split_log_plus1;/* 0 = automatic; k + 1 cuts every bucket's entry list into 2^k pieces (k <= 4) */
-    int slice_len;      /* buckets per lane of the bucket reduction; 0 = automatic */
+    int slice_len;      /* ZK_MSM_FLAG_SLICE_REDUCE only: buckets per lane of the slice reduction; 0 = automatic */
     int big_threshold;  /* buckets longer than this take the cooperative segment path; 0 = 2 x mean + 64 */
     int waves_per_simd; /* accumulate-kernel waves launched per SIMD; 0 = what the kernel was compiled for */
     int flags;          /* ZK_MSM_FLAG_* */
@@ -87,6 +87,7 @@ typedef struct {
     int reserved[2];
 } zk_msm_opts;
 #define ZK_MSM_FLAG_NO_HOT_HELP 1   /* skewed witnesses: leave hot regions to their own sort workgroup */
+#define ZK_MSM_FLAG_SLICE_REDUCE 2  /* bucket reduction by slices + multiplier (round 1) instead of row / column sums: A/B */
 
 /* NTT plan knobs (process-wide, zk_ntt_configure).  Zero-initialise for defaults. */
 typedef struct {

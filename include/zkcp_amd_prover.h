@@ -142,6 +142,13 @@ int zk_ipa_fold_bases_device(zk_curve_t c, void *g_affine_dev, uint64_t half, co
 int zk_ipa_virtual_scalars_device(zk_field_t f, const void *p_dev, const void *w_dev, uint64_t m0, uint64_t cur, void *sl_dev, void *sr_dev,
                                   void *hip_stream);
 int zk_ipa_update_weights_device(zk_field_t f, void *w_dev, uint64_t m0, uint64_t bit, const void *u_mont_host, void *hip_stream);
+/* ... and to leave the fold-free form after r of those rounds: the generators r calls of parallel_generator_collapse would
+ * have produced, g_out[i] = sum_{t < m0 / cur} W[t cur] G0[t cur + i] for i < cur (affine (x, y) Montgomery, identity (0, 0)),
+ * as cur multi-scalar multiplications that share their m0 / cur <= 4096 scalars.  The later rounds then run over g_out
+ * (zk_bases_adopt_device) with fresh weights: a few full-size rounds cost a full-size MSM each, the many small ones do not.
+ * Synchronises hip_stream: g_out is complete on return. */
+int zk_ipa_collapse_device(zk_curve_t c, uint64_t bases_handle, const void *w_dev, uint64_t m0, uint64_t cur, void *g_out_affine_dev,
+                           void *hip_stream);
 
 /* The quotient numerator: one stack program evaluated at every row of the extended domain (plonk/prover.rs: each gate's
  * Expression over advice / fixed / instance columns with rotations, folded with y).  A rotation by r rows is a shift of

@@ -291,8 +291,25 @@ def check_msm_slice_lengths(zk, cname, n, window_bits):
     exp = orc.msm_ark(cname, pts, sc, threads=8)
     bases = zk.Bases(cname, pts)
     for L in (1, 2, 3, 8, 64, 1024):
-        got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits, slice_len=L))
+        got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits, slice_len=L, slice_reduce=True))
         assert (got == exp).all(), (cname, L)
+    bases.free()
+
+
+def check_msm_axis_reduce(zk, cname, n, window_bits_list, windows=None, seed=29):
+    """the default bucket reduction (row / column sums, suffix scan + tree) over the shapes of its matrix: one row
+    (c = 2, 3), rows = columns (odd c), rows = columns / 2 (even c), more columns than one workgroup holds (c = 16 on the
+    G2 point types: two blocks per axis, combined on the host); against the slice form and the oracle"""
+    pts = bases_for(cname, n)
+    sc = scalars_for(cname, n, seed)
+    exp = orc.msm_ark(cname, pts, sc, threads=8) if windows is None else None
+    bases = zk.Bases(cname, pts)
+    for wb in window_bits_list:
+        got = zk.msm(bases, sc, window_bits=wb, windows=windows)
+        ref = zk.msm(bases, sc, window_bits=wb, windows=windows, slice_reduce=True)
+        assert (affine_of(zk, cname, got) == affine_of(zk, cname, ref)).all(), (cname, wb)
+        if exp is not None:
+            assert (affine_of(zk, cname, got) == exp).all(), (cname, wb)
     bases.free()
 
 
@@ -678,12 +695,14 @@ def check_ipa(zk, cname, k, seed=13):
     rounds, c_fin, b_fin, g_fin = h2.ipa_argument(cname, pp, b, g_py, us)
     ipa = zk.halo2.IpaProver(cname, to_device(zk, _monts(sf, pp)), to_device(zk, _monts(sf, b)), to_device(zk, gens.copy()))
     aff = lambda P: np.zeros(2 * L, dtype=np.uint64) if P is None else np.concatenate([orc.int_to_limbs(pyref.mont(bf, c), L) for c in P])
+    g_after = {}
     for j in range(k):
         Lj, Rj, vl, vr = ipa.round()
         eL, eR, evl, evr = rounds[j]
         assert (zk.point_to_affine(cname, Lj) == aff(eL)).all() and (zk.point_to_affine(cname, Rj) == aff(eR)).all(), (cname, k, j)
         assert (vl == _monts(sf, [evl])[0]).all() and (vr == _monts(sf, [evr])[0]).all()
         ipa.fold(_monts(sf, [us[j]])[0])
+        g_after[j + 1] = to_host(zk, ipa.g)[:n >> (j + 1)].copy()
     assert (to_host(zk, ipa.p)[0] == _monts(sf, [c_fin])[0]).all() and (to_host(zk, ipa.b)[0] == _monts(sf, [b_fin])[0]).all()
     assert (to_host(zk, ipa.g)[0] == aff(g_fin)).all()
     ipa.free()
@@ -699,6 +718,22 @@ def check_ipa(zk, cname, k, seed=13):
         vipa.fold(_monts(sf, [us[j]])[0])
     assert (to_host(zk, vipa.p)[0] == _monts(sf, [c_fin])[0]).all()
     assert (zk.point_to_affine(cname, vipa.folded_generator()) == aff(g_fin)).all()
+    vipa.free()
+    # ... and leaving the fold-free form on the way: after some rounds the generators are materialised in one step
+    # (zk_ipa_collapse_device) -- they must be what the literal folds left -- and the later rounds run over them
+    stops = sorted({min(3, k), min(5, k), k})
+    vipa = zk.halo2.IpaProverVirtual(cname, to_device(zk, _monts(sf, pp)), to_device(zk, _monts(sf, b)), srs, new_buffer)
+    for j in range(k):
+        Lj, Rj, vl, vr = vipa.round()
+        eL, eR, evl, evr = rounds[j]
+        assert (zk.point_to_affine(cname, Lj) == aff(eL)).all() and (zk.point_to_affine(cname, Rj) == aff(eR)).all(), (cname, k, j, "collapsed")
+        vipa.fold(_monts(sf, [us[j]])[0])
+        if j + 1 in stops:
+            g = to_host(zk, vipa.collapse())
+            assert (g == g_after[j + 1]).all(), (cname, k, j + 1, "collapse")
+    assert (g[0] == aff(g_fin)).all()
+    assert (to_host(zk, vipa.p)[0] == _monts(sf, [c_fin])[0]).all()
+    vipa.free()
     srs.free()
 
 

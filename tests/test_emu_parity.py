@@ -108,6 +108,13 @@ def test_msm_slice_lengths(zk):
     ps.check_msm_slice_lengths(zk, "Bn254G2", 60, 6)
 
 
+def test_msm_axis_reduce(zk):
+    ps.check_msm_axis_reduce(zk, "Vesta", 700, [2, 3, 4, 5, 8, 11])
+    ps.check_msm_axis_reduce(zk, "Bn254G2", 300, [3, 6, 9])
+    ps.check_msm_axis_reduce(zk, "Bls381G2", 200, [16], windows=(3, 5))     # 256 columns > 128 lanes: two blocks
+    ps.check_msm_axis_reduce(zk, "Pallas", 300, [16, 15], windows=(0, 2))
+
+
 def test_fixed_base_msm(zk):
     ps.check_fixed_base_msm(zk, "Vesta", 21)
     ps.check_fixed_base_msm(zk, "Bn254G2", 13)

@@ -151,6 +151,12 @@ def test_msm_slice_lengths(zk, cname):
     ps.check_msm_slice_lengths(zk, cname, 1 << 13, 12)
 
 
+@pytest.mark.parametrize("cname,n,wbs", [("Vesta", 1 << 14, [2, 3, 4, 7, 10, 13, 15, 16]), ("Bls381G1", 1 << 13, [5, 12, 16]),
+                                         ("Bn254G2", 1 << 12, [3, 9, 14, 16]), ("Bls381G2", 1 << 12, [8, 15, 16])])
+def test_msm_axis_reduce(zk, cname, n, wbs):
+    ps.check_msm_axis_reduce(zk, cname, n, wbs)
+
+
 @pytest.mark.parametrize("name,log_in,logn", [("PallasFp", 10, 13), ("Bls381Fr", 17, 20), ("Bn254Fr", 12, 12), ("PallasFq", 18, 21)])
 def test_ntt_extend(zk, name, log_in, logn):
     ps.check_ntt_extend(zk, name, log_in, logn, threads=32)

@@ -26,8 +26,9 @@ for logn in range(lo, hi + 1):
     d_sc = d_all[:n]
     default_c = max(4, min(16, logn - 4))          # msm_pick_c
     ref = None
-    for c in sorted({default_c, max(4, default_c - 2), min(16, default_c + 2), min(16, default_c + 4)}):
-        kw = {"window_bits": c}
+    cs = sorted({default_c, max(4, default_c - 2), min(16, default_c + 2), min(16, default_c + 4), 16})
+    for c, slice_reduce in [(c, s) for c in cs for s in (False, True)]:
+        kw = {"window_bits": c, "slice_reduce": slice_reduce}
         for _ in range(2):
             out = zk.msm(bases, d_sc, **kw)
         acc = {}
@@ -44,5 +45,5 @@ for logn in range(lo, hi + 1):
         if ref is None:
             ref = aff
         ok = bool((aff == ref).all())
-        print(f"logn={logn} c={c}{'*' if c == default_c else ' '} {'ok' if ok else 'MISMATCH'} wall={wall:.3f} ",
+        print(f"logn={logn} c={c}{'*' if c == default_c else ' '} {'slice' if slice_reduce else 'axes '} {'ok' if ok else 'MISMATCH'} wall={wall:.3f} ",
               {k[:-3]: round(v, 3) for k, v in acc.items() if k.endswith("_ms")}, flush=True)
