@@ -87,7 +87,7 @@ def setup():
                          "that for the first --ipa-collapse-after rounds, then materialises the surviving generators in one step "
                          "(zk_ipa_collapse_device) and continues over them; 'fold' collapses the generator vector every round as upstream "
                          "does (one scalar multiplication per surviving point)")
-    ap.add_argument("--ipa-collapse-after", type=int, default=8)
+    ap.add_argument("--ipa-collapse-after", type=int, default=6)
     ap.add_argument("--ntt-limbs", type=int, default=0, choices=[0, 32], help="0: lazy 29-bit limbs inside the NTT tiles (default); 32: saturated words (A/B)")
     args = ap.parse_args()
 

@@ -17,10 +17,14 @@ int msm_pick_c(uint64_t n, int requested) {
     if (requested > 0) return requested < 2 ? 2 : (requested > 16 ? 16 : requested);  // digits are stored as u16 codes
     int l = 0;
     while ((1ull << l) < n) l++;
-    int c = l - 4;  // ~2^5 points per bucket per window
-    if (c < 4) c = 4;
-    if (c > 16) c = 16;
-    return c;
+    // Measured on one MI355X (profiles/r02_g_msm_size_sweep_vesta.txt): below 2^20 points the fixed costs decide -- the bucket
+    // reduction's dependent additions, the host Horner (c doublings per window), the sort launches -- not the additions per
+    // point, so the rule "2^5 points per bucket" (c = log2 n - 4) of round 1 was 20 - 45 % slow from 2^15 to 2^19.
+    if (l >= 16) return 16;
+    if (l == 15) return 15;
+    if (l == 14) return 10;
+    if (l == 13) return 9;
+    return 8;
 }
 
 // the scratch set of a caller stream: found by stream, created on first use, least-recently-used one recycled (after its

@@ -45,7 +45,8 @@ int msm_finish_impl(MsmJob& job, void* out_jac) {
             to_host<C>(r, ps);
         };
         for (int w = job.nw - 1; w >= 0; w--) {
-            for (int k = 0; k < job.c; k++) xyzz_dbl(htotal);
+            // axes form: acc 2^c + (2^lc rows + columns) = (acc 2^(c - lc) + rows) 2^lc + columns -- no extra doublings
+            for (int k = 0; k < (job.axes ? job.c - (int)job.log_cols : job.c); k++) xyzz_dbl(htotal);
             if (!job.axes) {
                 for (uint32_t i = 0; i < job.per; i++) {
                     load(hp, (size_t)w * job.per + i);
@@ -76,9 +77,9 @@ int msm_finish_impl(MsmJob& job, void* out_jac) {
                     for (uint32_t k = 0; k < job.log_tl; k++) xyzz_dbl(acc);
                     xyzz_add(tot, acc);
                 }
-                if (axis == 0)
-                    for (uint32_t k = 0; k < job.log_cols; k++) xyzz_dbl(tot);
                 xyzz_add(htotal, tot);
+                if (axis == 0)
+                    for (uint32_t k = 0; k < job.log_cols; k++) xyzz_dbl(htotal);
             }
         }
         for (int k = 0; k < job.c * job.w0; k++) xyzz_dbl(htotal);
@@ -158,7 +159,12 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         }
         const uint32_t nbuckets = (uint32_t)nw_all * sh.nbk;
         const uint32_t nreg = (uint32_t)nw_all * sh.nranges;                  // (window, bucket range) regions
-        const uint32_t nblocks = (uint32_t)((n + MSM_SBLK - 1) / MSM_SBLK);    // scalar blocks of the count / stage kernels
+        // scalar blocks of the count / stage kernels: 4096 scalars each at full size; a small input (the later IPA rounds, small
+        // keys) would leave all of its digit extraction to a handful of workgroups (72 us for 2^12 scalars in one), so it gets
+        // blocks as small as 256 scalars, enough for >= 64 workgroups
+        sh.sblk = MSM_SBLK;
+        while (sh.sblk > 256 && (n + sh.sblk - 1) / sh.sblk < 64) sh.sblk >>= 1;
+        const uint32_t nblocks = (uint32_t)((n + sh.sblk - 1) / sh.sblk);
         if (nreg > 4096 || sh.nranges > 64) return ZK_ERR_UNSUPPORTED;         // LDS tables of those kernels (c <= 16: <= 1024, 64)
         if ((uint64_t)n * (uint64_t)nw_all >= (1ull << 32)) return ZK_ERR_UNSUPPORTED;   // entry positions are u32 (2^27 points x 16 windows fit)
         // counts | offs | order | wg_total | region_base
@@ -204,7 +210,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         hipEvent_t* ev = job.ev;   // [0] begin, [1] counted, [2] staged, [3] sorted, [4] accumulated, [5] reduced, [6] partials on the host
         HIP_TRY(hipEventRecord(ev[0], st));
         // ---- sort: partition the digits by (window, bucket range), then counting-sort every region in LDS
-        const unsigned dblk = n >= 8192 ? 1024u : 256u;   // small problems: fewer lanes, cheaper barriers
+        const unsigned dblk = sh.sblk >= 4096 ? 1024u : 256u;   // small problems: fewer lanes, cheaper barriers
         ZK_LAUNCH((msm_digits_kernel<C>), nblocks, dblk, (size_t)nreg * 4, st, d_scalars, sh, digits, blockcnt);
         auto lanes_for = [](uint32_t items) {   // workgroup size for a scan over `items` values: a power of two in [64, 1024]
             unsigned b = 64;
@@ -214,7 +220,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         ZK_LAUNCH((msm_region_scan_kernel<void>), nreg, lanes_for(nblocks), 0, st, blockcnt, nblocks, wg_total);
         ZK_LAUNCH((msm_region_base_kernel<void>), 1, lanes_for(nreg), 0, st, (const uint32_t*)wg_total, nreg, region_base);
         HIP_TRY(hipEventRecord(ev[1], st));
-        ZK_LAUNCH((msm_stage_kernel<void>), nblocks * (unsigned)nw_all, dblk, (size_t)MSM_SBLK * 8 + (size_t)(3 * sh.nranges + 1) * 4, st,
+        ZK_LAUNCH((msm_stage_kernel<void>), nblocks * (unsigned)nw_all, dblk, (size_t)sh.sblk * 8 + (size_t)(3 * sh.nranges + 1) * 4, st,
                   (const uint16_t*)digits, sh, (const uint32_t*)blockcnt, (const uint32_t*)wg_total, (const uint32_t*)region_base, nblocks,
                   stage_idx, stage_low);
         HIP_TRY(hipEventRecord(ev[2], st));
@@ -227,7 +233,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         const uint64_t cl64 = 4 * (n / sh.nranges) + 4 * (uint64_t)cap;
         const uint32_t chunk_limit = cl64 < 0xffffffffull ? (uint32_t)cl64 : 0xffffffffu;
         // hot regions (skewed witnesses) are histogrammed and scattered by MSM_HOT_SLICES workgroups each, around the sort kernel
-        const bool hot_help = nreg <= 1024 && !tu.no_hot_help;
+        const bool hot_help = nreg <= 1024 && !tu.no_hot_help && n >= 32768;   // a small input's hot region is one sort workgroup's work anyway
         uint32_t* hot_flag = nullptr;
         uint32_t* hot_list = nullptr;
         uint32_t* gcur = nullptr;
@@ -558,11 +564,17 @@ int ipa_collapse_run(DeviceCtx& dc, const BasesCopy& bc, uint64_t base_n, const 
         HIP_TRY(hipStreamSynchronize(st));
         return ZK_OK;
     }
-    int lt = 0;
-    while ((1u << lt) < T) lt++;
-    int c = lt - 2;                      // ~8 entries per bucket
-    if (c < 2) c = 2;
-    if (c > 8) c = 8;
+    int c = 2;                           // per output and window: T additions into the buckets + 2 per bucket to reduce them
+    {
+        uint64_t best = ~0ull;
+        for (int cc = 2; cc <= 8; cc++) {
+            const uint64_t cost = ((uint64_t)T + (1ull << cc)) * (uint64_t)msm_windows<C>(cc);
+            if (cost < best) {
+                best = cost;
+                c = cc;
+            }
+        }
+    }
     const uint32_t nbk = 1u << (c - 1);
     const uint32_t nwin = (uint32_t)msm_windows<C>(c);
     StreamScratch* ss = nullptr;

@@ -46,6 +46,7 @@ struct MsmShape {
     int mont;         // scalars arrive in Montgomery form (halo2) rather than canonical (ark BigInt)
     uint32_t big_thresh;  // buckets longer than this take the cooperative path
     int split_log;        // every bucket's entry list is cut into 2^split_log pieces summed by different lanes (msm_combine_sub_kernel adds them)
+    uint32_t sblk;        // scalars per workgroup of the digit / stage kernels: MSM_SBLK, less for small inputs (>= 64 workgroups)
 };
 
 template <int N>
@@ -64,7 +65,7 @@ __device__ __forceinline__ uint32_t bits_at(const uint32_t (&s)[N], int start, i
 }
 
 constexpr uint32_t MSM_RANGE = 512;   // buckets per (window, range) region of the sort
-constexpr uint32_t MSM_SBLK = 4096;   // scalars per workgroup of the digit / stage kernels (1024 lanes x 4)
+constexpr uint32_t MSM_SBLK = 4096;   // scalars per workgroup of the digit / stage kernels (1024 lanes x 4) at full size: MsmShape::sblk
 
 // u16 digit code: two's complement of the signed digit; positive magnitudes reach 2^15 (0x8000),
 // negative ones only 2^15 - 1, so the code is unambiguous:  neg <=> code > 0x8000.
@@ -98,7 +99,7 @@ __device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* ctr, uint32_t key, bo
     return 0;
 }
 
-// grid = ceil(n / MSM_SBLK).  Writes the digit codes window-major (digits[w * n + i]) and counts this block's non-zero
+// grid = ceil(n / sh.sblk).  Writes the digit codes window-major (digits[w * n + i]) and counts this block's non-zero
 // digits per region: blockcnt[region * nblocks + block], region = window * nranges + range
 template <class C>
 __global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh,
@@ -113,8 +114,8 @@ __global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::F
     // same-address LDS atomics serialise lane by lane (0.12 ms for 2^12 scalars x 32 windows in one workgroup) -- one
     // aggregated atomic per wave and counter instead.  Trip counts are wave-uniform: no lane leaves the loops early.
     const bool agg = sh.nranges <= 8;
-    for (uint32_t k = threadIdx.x; k < MSM_SBLK; k += blockDim.x) {
-        const uint32_t i = blockIdx.x * MSM_SBLK + k;
+    for (uint32_t k = threadIdx.x; k < sh.sblk; k += blockDim.x) {
+        const uint32_t i = blockIdx.x * sh.sblk + k;
         const bool valid = i < sh.n;
         Fe<Fr> x;
         fe_zero(x);
@@ -195,12 +196,12 @@ __global__ void __launch_bounds__(1024) msm_region_base_kernel(const uint32_t* _
     }
 }
 
-// grid = nblocks * nw: workgroup (block b, window w) partitions the <= MSM_SBLK digits of its block by bucket range INSIDE
+// grid = nblocks * nw: workgroup (block b, window w) partitions the <= sh.sblk digits of its block by bucket range INSIDE
 // LDS and then copies every range's chunk to its place in the region (window, range): entry = (point index | sign << 31)
 // in stage_idx and the bucket number inside the range in stage_low.  The copy is what makes this cheap: a lane-per-digit
 // scatter would issue one 4-byte store request per digit to L2 (33 M requests at 2^20 x 16), the chunk copy issues a
 // few requests per 64-entry chunk.
-// LDS: e_idx[MSM_SBLK] u32 | starts[R + 1] | gdst[R] | lcur[R] | e_low[MSM_SBLK] u16 | e_h[MSM_SBLK] u16      (R = nranges <= 64)
+// LDS: e_idx[sblk] u32 | starts[R + 1] | gdst[R] | lcur[R] | e_low[sblk] u16 | e_h[sblk] u16      (R = nranges <= 64)
 template <class Tag>
 __global__ void __launch_bounds__(1024) msm_stage_kernel(const uint16_t* __restrict__ digits, MsmShape sh, const uint32_t* __restrict__ blockoff,
                                                          const uint32_t* __restrict__ wg_total, const uint32_t* __restrict__ region_base,
@@ -208,11 +209,11 @@ __global__ void __launch_bounds__(1024) msm_stage_kernel(const uint16_t* __restr
     ZK_DYN_SHARED(uint32_t, lds);
     const uint32_t R = sh.nranges;
     uint32_t* e_idx = lds;
-    uint32_t* starts = e_idx + MSM_SBLK;
+    uint32_t* starts = e_idx + sh.sblk;
     uint32_t* gdst = starts + (R + 1);
     uint32_t* lcur = gdst + R;
     uint16_t* e_low = reinterpret_cast<uint16_t*>(lcur + R);
-    uint16_t* e_h = e_low + MSM_SBLK;
+    uint16_t* e_h = e_low + sh.sblk;
     const uint32_t tid = threadIdx.x, nth = blockDim.x;
     const uint32_t blk = blockIdx.x % nblocks, wl = blockIdx.x / nblocks;
     const uint32_t rb_log = 31u - (uint32_t)__clz(sh.rb);
@@ -236,8 +237,8 @@ __global__ void __launch_bounds__(1024) msm_stage_kernel(const uint16_t* __restr
         __syncthreads();
     }
     const uint16_t* row = digits + (uint64_t)wl * sh.n;
-    for (uint32_t k = tid; k < MSM_SBLK; k += nth) {
-        const uint32_t i = blk * MSM_SBLK + k;
+    for (uint32_t k = tid; k < sh.sblk; k += nth) {
+        const uint32_t i = blk * sh.sblk + k;
         if (i >= sh.n) break;
         bool neg;
         const uint32_t mag = digit_mag(row[i], neg);

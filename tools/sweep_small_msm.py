@@ -24,9 +24,9 @@ d_all = torch.from_numpy(ps.scalars_for(curve, N, 0xC0DE).view(np.int64)).cuda()
 for logn in range(lo, hi + 1):
     n = 1 << logn
     d_sc = d_all[:n]
-    default_c = max(4, min(16, logn - 4))          # msm_pick_c
+    default_c = zk.load().zk_msm_window_bits(zk.curve_id(curve), n, 0)   # msm_pick_c
     ref = None
-    cs = sorted({default_c, max(4, default_c - 2), min(16, default_c + 2), min(16, default_c + 4), 16})
+    cs = sorted({default_c, max(4, logn - 4), 8, 12, 16})
     for c, slice_reduce in [(c, s) for c in cs for s in (False, True)]:
         kw = {"window_bits": c, "slice_reduce": slice_reduce}
         for _ in range(2):
