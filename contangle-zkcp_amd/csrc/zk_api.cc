@@ -23,7 +23,6 @@ int msm_pick_c(uint64_t n, int requested) {
     if (l >= 16) return 16;
     if (l == 15) return 15;
     if (l == 14) return 10;
-    if (l == 13) return 9;
     return 8;
 }
 
