@@ -87,7 +87,7 @@ def setup():
                          "that for the first --ipa-collapse-after rounds, then materialises the surviving generators in one step "
                          "(zk_ipa_collapse_device) and continues over them; 'fold' collapses the generator vector every round as upstream "
                          "does (one scalar multiplication per surviving point)")
-    ap.add_argument("--ipa-collapse-after", type=int, default=6)
+    ap.add_argument("--ipa-collapse-after", default="6", help="round count(s) after which the generators are materialised, e.g. 6 or 6,10")
     ap.add_argument("--ntt-limbs", type=int, default=0, choices=[0, 32], help="0: lazy 29-bit limbs inside the NTT tiles (default); 32: saturated words (A/B)")
     args = ap.parse_args()
 
@@ -337,6 +337,8 @@ def bench_halo2(e):
             dom.lagrange_to_coeff(d_ext[c][:n], stream=stream)
             dom.coeff_to_extended(d_ext[c], stream=stream)
 
+    collapse_at = {int(x) for x in str(a.ipa_collapse_after).split(",") if x.strip()}
+
     def commit_batch(bases, cols):
         if a.serial:
             return [e.zkdist.msm_sharded(bases, cols[c], montgomery=True, window_bits=a.window_bits, stream=e.st) for c in range(cols.shape[0])]
@@ -401,7 +403,7 @@ def bench_halo2(e):
         for j in range(k):
             ipa.round(sharded=e.world > 1)
             ipa.fold(us[j])
-            if a.ipa == "collapse" and j + 1 == a.ipa_collapse_after and j + 1 < k:
+            if a.ipa == "collapse" and (j + 1) in collapse_at and j + 1 < k:
                 ipa.collapse()
         ipa.free()
         torch.cuda.synchronize()
@@ -421,7 +423,7 @@ def bench_halo2(e):
                          "%d-op expression over 27 extended columns, divide by Z_H, extended_to_coeff, 8 h-piece commits ; opening: %d-round IPA "
                          "(2 MSMs + 2 inner products + 3 folds per round; generators %s)" % (
                              k, len(prog), k, {"fold": "folded every round", "virtual": "never folded: every MSM over the SRS",
-                                               "collapse": "folded once, after round %d, by zk_ipa_collapse_device" % a.ipa_collapse_after}[a.ipa]),
+                                               "collapse": "materialised after round(s) %s by zk_ipa_collapse_device" % a.ipa_collapse_after}[a.ipa]),
                          {"rows_per_step": n, "msm_curve": curve, "msm_points": n, "msm_windows_done": 16, "msm_windows": 16,
                           "window_bits": 16, "columns": NCOL, "full_size_msms_per_step": n_msm, "ntt_2p%d_per_step" % k: 19, "ntt_2p%d_per_step" % ext: 20,
                           "streams": "one (serial)" if a.serial else "MSM batches on two library streams + NTT chains on a third",

@@ -1119,6 +1119,33 @@ API int zk_ipa_virtual_scalars_device(zk_field_t f, const void* p, const void* w
     FIELD_SWITCH(f, return ipa_virtual_scalars_run<F>((const Fe<F>*)p, (const Fe<F>*)w, (Fe<F>*)sl, (Fe<F>*)sr, m0, cur, (hipStream_t)stream));
     return ZK_ERR_INVALID_ARG;
 }
+API int zk_ipa_round_device(zk_curve_t c, uint64_t handle, const void* p, const void* b, const void* w, uint64_t m0, uint64_t cur, void* s_dev,
+                            void* lr_out, void* v_out, void* stream) {
+    if (!p || !b || !w || !s_dev || !lr_out || !v_out || !aligned16(p) || !aligned16(b) || !aligned16(w) || !aligned16(s_dev))
+        return ZK_ERR_INVALID_ARG;
+    const int fi = zk_curve_scalar_field(c);
+    if (fi < 0) return ZK_ERR_INVALID_ARG;
+    const zk_field_t f = (zk_field_t)fi;
+    size_t fbytes = 0;
+    FIELD_SWITCH(f, fbytes = sizeof(Fe<F>));
+    unsigned char* sl = (unsigned char*)s_dev;
+    unsigned char* sr = sl + (size_t)m0 * fbytes;
+    {
+        DEVICE_ENTRY(s_dev);
+        int st = ZK_ERR_INVALID_ARG;
+        FIELD_SWITCH(f, st = ipa_round_begin_run<F>(dc, (const Fe<F>*)p, (const Fe<F>*)b, (const Fe<F>*)w, (Fe<F>*)sl, (Fe<F>*)sr, m0, cur,
+                                                     (hipStream_t)stream));
+        ZK_TRY(st);
+    }
+    // both MSMs over the resident generators (two library streams, forked behind the kernels above); dc.mu is not held here
+    ZK_TRY(zk_msm_batch_device(c, handle, s_dev, m0, 2, m0, 1, nullptr, lr_out, stream));
+    {
+        DEVICE_ENTRY(s_dev);
+        int st = ZK_ERR_INVALID_ARG;
+        FIELD_SWITCH(f, st = ipa_round_end_run<F>(dc, (hipStream_t)stream, v_out, (unsigned char*)v_out + fbytes));
+        return st;
+    }
+}
 API int zk_ipa_update_weights_device(zk_field_t f, void* w, uint64_t m0, uint64_t bit, const void* u, void* stream) {
     if (!w || !u || !aligned16(w)) return ZK_ERR_INVALID_ARG;
     DEVICE_ENTRY(w);

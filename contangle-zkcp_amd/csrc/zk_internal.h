@@ -111,6 +111,10 @@ struct StreamScratch {
     uint64_t stamp = 0;
     DevBuf ntt_tmp, fb_table, fb_tmp;
     DevBuf poly_a, poly_b, poly_tot;   // numerators / denominators / block totals of the grand-product and IPA helpers
+    void* pinned = nullptr;            // small pinned host buffer: results that are read back without stalling the stream at once
+    size_t pinned_cap = 0;
+    hipEvent_t pinned_ev = nullptr;    // recorded after the copies into `pinned`
+    uint32_t ip_blocks = 0;            // partial sums per inner product waiting in `pinned` (zk_ipa_round_device)
 };
 
 constexpr int ZK_MAX_JOBS = 4;

@@ -12,19 +12,6 @@ inline double now_ms() {
 
 // partial sums leave the device in the kernels' view CK of the curve (C itself, or its F29 view) and are brought back
 // to the caller's limb form here
-template <class C>
-inline void partial_to_std(XYZZ<C>& r, const XYZZ<C>& p) {
-    r = p;
-}
-template <class C>
-inline void partial_to_std(XYZZ<C>& r, const XYZZ<C29<C>>& p) {
-    xyzz29_to_std<C>(r, p);
-}
-template <class C>
-inline void partial_to_std(XYZZ<C>& r, const XYZZ<C29x2<C>>& p) {
-    xyzz29_to_std<C>(r, p);
-}
-
 // Host tail of one MSM (per curve): Horner over the job's windows, high to low, then the shift by 2^(c*w0) -- on 64-bit
 // host limbs, from the per-window partial sums the job copied to pinned memory.  Runs in zk_msm_collect, i.e. after the
 // caller has had the chance to enqueue the next MSM: the GPU never waits for it.

@@ -1055,6 +1055,19 @@ __global__ void __launch_bounds__(256) msm_axis_fold_kernel(const XYZZ<C>* __res
 // Row_hi has weight hi, so Row_0 drops out and x_t = Row_{t + 1}; 0 for the columns), infinity beyond the axis.
 //   out[2 i]     = sum_t (t + 1) x_t         (suffix scan, then a tree over the suffix sums)
 //   out[2 i + 1] = sum_t x_t                 (the first suffix sum)
+// the partial sums go to the host in the kernel view's limb form: the host converts (partial_to_std) while it adds them up
+template <class CB>
+inline void partial_to_std(XYZZ<CB>& r, const XYZZ<CB>& p) {
+    r = p;
+}
+template <class CB>
+inline void partial_to_std(XYZZ<CB>& r, const XYZZ<C29<CB>>& p) {
+    xyzz29_to_std<CB>(r, p);
+}
+template <class CB>
+inline void partial_to_std(XYZZ<CB>& r, const XYZZ<C29x2<CB>>& p) {
+    xyzz29_to_std<CB>(r, p);
+}
 template <class C>
 __global__ void __launch_bounds__(256) msm_axis_weighted_kernel(const XYZZ<C>* __restrict__ elem, XYZZ<C>* __restrict__ out, MsmAxes A,
                                                                 uint32_t row_blocks, uint32_t col_blocks) {

@@ -40,6 +40,10 @@ int vec_fold_run(Fe<F>* a, uint64_t half, const Fe<F>& c, hipStream_t st);
 template <class F>
 int ipa_virtual_scalars_run(const Fe<F>* p, const Fe<F>* W, Fe<F>* SL, Fe<F>* SR, uint64_t m0, uint64_t cur, hipStream_t st);
 template <class F>
+int ipa_round_begin_run(DeviceCtx& dc, const Fe<F>* p, const Fe<F>* b, const Fe<F>* W, Fe<F>* SL, Fe<F>* SR, uint64_t m0, uint64_t cur, hipStream_t st);
+template <class F>
+int ipa_round_end_run(DeviceCtx& dc, hipStream_t st, void* vl_host, void* vr_host);
+template <class F>
 int ipa_update_weights_run(Fe<F>* W, uint64_t m0, uint64_t bit, const Fe<F>& u, hipStream_t st);
 template <class F>
 int expr_eval_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const Fe<F>* consts,

@@ -14,6 +14,8 @@ template int lookup_product_run<ZK_FIELD>(DeviceCtx&, const Fe<ZK_FIELD>*, const
 template int inner_product_run<ZK_FIELD>(DeviceCtx&, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, uint64_t, void*, hipStream_t);
 template int vec_fold_run<ZK_FIELD>(Fe<ZK_FIELD>*, uint64_t, const Fe<ZK_FIELD>&, hipStream_t);
 template int ipa_virtual_scalars_run<ZK_FIELD>(const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, uint64_t, uint64_t, hipStream_t);
+template int ipa_round_begin_run<ZK_FIELD>(DeviceCtx&, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, uint64_t, uint64_t, hipStream_t);
+template int ipa_round_end_run<ZK_FIELD>(DeviceCtx&, hipStream_t, void*, void*);
 template int ipa_update_weights_run<ZK_FIELD>(Fe<ZK_FIELD>*, uint64_t, uint64_t, const Fe<ZK_FIELD>&, hipStream_t);
 template int expr_eval_run<ZK_FIELD>(DeviceCtx&, const zk_expr_op*, uint32_t, const void* const*, uint32_t, const Fe<ZK_FIELD>*, uint32_t, uint32_t, uint32_t,
                                      Fe<ZK_FIELD>*, hipStream_t);

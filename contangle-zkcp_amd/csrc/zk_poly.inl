@@ -118,6 +118,56 @@ int inner_product_run(DeviceCtx& dc, const Fe<F>* a, const Fe<F>* b, uint64_t n,
     return ZK_OK;
 }
 
+// One IPA round's scalar side without a host round trip per value (zk_ipa_round_device): the fold-free round's MSM scalars
+// and both inner products <p'_hi, b_lo>, <p'_lo, b_hi> are enqueued, their per-workgroup partial sums copied to pinned host
+// memory behind an event; ipa_round_end_run adds them up after the round's MSMs have been collected.
+template <class F>
+int ipa_round_begin_run(DeviceCtx& dc, const Fe<F>* p, const Fe<F>* b, const Fe<F>* W, Fe<F>* SL, Fe<F>* SR, uint64_t m0, uint64_t cur,
+                        hipStream_t st) {
+    ZK_TRY(ipa_virtual_scalars_run<F>(p, W, SL, SR, m0, cur, st));
+    const uint64_t half = cur / 2;
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    uint64_t blocks = (half + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const size_t bytes = 2 * blocks * sizeof(Fe<F>);
+    ZK_TRY(ws_get(ss->poly_tot, bytes));
+    if (ss->pinned_cap < bytes) {
+        if (ss->pinned) hipHostFree(ss->pinned);
+        ss->pinned = nullptr;
+        ss->pinned_cap = 0;
+        HIP_TRY(hipHostMalloc(&ss->pinned, 2 * 1024 * sizeof(Fe<F>), 0));
+        ss->pinned_cap = 2 * 1024 * sizeof(Fe<F>);
+    }
+    if (!ss->pinned_ev) HIP_TRY(hipEventCreate(&ss->pinned_ev));
+    Fe<F>* tot = (Fe<F>*)ss->poly_tot.p;
+    if (half) {
+        ZK_LAUNCH((inner_product_kernel<F>), (unsigned)blocks, 256, 0, st, p + half, b, half, tot);
+        ZK_LAUNCH((inner_product_kernel<F>), (unsigned)blocks, 256, 0, st, p, b + half, half, tot + blocks);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ss->pinned, tot, bytes, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(ss->pinned_ev, st));
+    ss->ip_blocks = half ? (uint32_t)blocks : 0;
+    return ZK_OK;
+}
+template <class F>
+int ipa_round_end_run(DeviceCtx& dc, hipStream_t st, void* vl_host, void* vr_host) {
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    if (!ss->pinned_ev) return ZK_ERR_INVALID_ARG;
+    HIP_TRY(hipEventSynchronize(ss->pinned_ev));
+    const Fe<F>* part = (const Fe<F>*)ss->pinned;
+    for (int k = 0; k < 2; k++) {
+        Fe<F> acc;
+        fe_zero(acc);
+        for (uint32_t i = 0; i < ss->ip_blocks; i++) fe_add(acc, acc, part[(size_t)k * ss->ip_blocks + i]);
+        host_store(k == 0 ? vl_host : vr_host, acc);
+    }
+    return ZK_OK;
+}
+
 template <class F>
 int vec_fold_run(Fe<F>* a, uint64_t half, const Fe<F>& c, hipStream_t st) {
     if (half == 0) return ZK_OK;

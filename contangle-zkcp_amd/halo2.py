@@ -19,7 +19,7 @@ from . import (Bases, _check, _np64, _ptr, base_limbs, curve_id, field_id, field
 
 PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo2_permutation_product_device",
                   "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
-                  "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device"]
+                  "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device", "zk_ipa_round_device"]
 
 
 def best_multiexp(coeffs, bases):
@@ -153,6 +153,7 @@ def _plib():
     lib.zk_ipa_virtual_scalars_device.argtypes = [i32, vp, vp, u64, u64, vp, vp, vp]
     lib.zk_ipa_update_weights_device.argtypes = [i32, vp, u64, u64, vp, vp]
     lib.zk_ipa_collapse_device.argtypes = [i32, u64, vp, u64, u64, vp, vp]
+    lib.zk_ipa_round_device.argtypes = [i32, u64, vp, vp, vp, u64, u64, vp, vp, vp, vp]
     lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     return lib
 
@@ -309,13 +310,17 @@ class IpaProverVirtual:
 
     def round(self, sharded=False):
         half = self.n // 2
+        if not sharded:     # the whole round in one call: scalars, inner products and both MSMs enqueued together
+            nl = _plib().zk_curve_base_limbs64(self.curve)
+            lr = np.zeros((2, 3 * nl), dtype=np.uint64)
+            v = np.zeros((2, 4), dtype=np.uint64)
+            _check(_plib().zk_ipa_round_device(self.curve, self.bases.handle, _ptr(self.p), _ptr(self.b), _ptr(self.W), self.m0, self.n,
+                                               _ptr(self.S), _ptr(lr), _ptr(v), ctypes.c_void_p(self.stream)), "zk_ipa_round_device")
+            return lr[0], lr[1], v[0], v[1]
         _check(_plib().zk_ipa_virtual_scalars_device(self.field, _ptr(self.p), _ptr(self.W), self.m0, self.n, _ptr(self.S[0]), _ptr(self.S[1]),
                                                      ctypes.c_void_p(self.stream)), "zk_ipa_virtual_scalars_device")
-        if sharded:
-            from . import dist as zkdist
-            L, R = zkdist.msm_batch_sharded(self.bases, self.S, montgomery=True, stream=self.stream)
-        else:
-            L, R = msm_batch(self.bases, self.S, montgomery=True, stream=self.stream)
+        from . import dist as zkdist
+        L, R = zkdist.msm_batch_sharded(self.bases, self.S, montgomery=True, stream=self.stream)
         vl = inner_product(self.field, self.p[half:self.n], self.b[:half], stream=self.stream)
         vr = inner_product(self.field, self.p[:half], self.b[half:self.n], stream=self.stream)
         return L, R, vl, vr

@@ -142,6 +142,11 @@ int zk_ipa_fold_bases_device(zk_curve_t c, void *g_affine_dev, uint64_t half, co
 int zk_ipa_virtual_scalars_device(zk_field_t f, const void *p_dev, const void *w_dev, uint64_t m0, uint64_t cur, void *sl_dev, void *sr_dev,
                                   void *hip_stream);
 int zk_ipa_update_weights_device(zk_field_t f, void *w_dev, uint64_t m0, uint64_t bit, const void *u_mont_host, void *hip_stream);
+/* One whole fold-free round in one call (zk_ipa_virtual_scalars_device + two zk_inner_product_device + zk_msm_batch_device without
+ * a host round trip per value): s_dev = scratch for 2 * m0 scalars; lr_out_host = L, R as Jacobian points (2 x 3 coordinates);
+ * v_out_mont_host = <p'_hi, b_lo>, <p'_lo, b_hi>. */
+int zk_ipa_round_device(zk_curve_t c, uint64_t bases_handle, const void *p_dev, const void *b_dev, const void *w_dev, uint64_t m0,
+                        uint64_t cur, void *s_dev, void *lr_out_host, void *v_out_mont_host, void *hip_stream);
 /* ... and to leave the fold-free form after r of those rounds: the generators r calls of parallel_generator_collapse would
  * have produced, g_out[i] = sum_{t < m0 / cur} W[t cur] G0[t cur + i] for i < cur (affine (x, y) Montgomery, identity (0, 0)),
  * as cur multi-scalar multiplications that share their m0 / cur <= 4096 scalars.  The later rounds then run over g_out
