@@ -76,7 +76,7 @@ def main():
                   "face value for msm_accumulate_kernel (random gathers of 64-byte packed records: uncalibrated pattern; Infinity-Cache hits are counted)")
     entry = {}
     for want, corr in (("msm_accumulate_kernel", 1.0), ("ntt_pass_kernel", 2.0)):
-        ks = [k for k in per if want in k and "big" not in k]
+        ks = [k for k in per if (want in k or (want == "ntt_pass_kernel" and "ntt_pass29_kernel" in k)) and "big" not in k]
         if not ks:
             continue
         fetch = sum(per[k].get("FETCH_SIZE", 0) for k in ks) * 1024
