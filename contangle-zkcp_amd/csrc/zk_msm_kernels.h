@@ -1006,7 +1006,7 @@ __global__ void __launch_bounds__(64) msm_axis_partials_kernel(const XYZZ<C>* __
 }
 
 // elem[e] = sum of part[e P .. e P + P): the rows (P = p_row) then the columns (P = p_col) of every window.  TW = min(P, 16)
-// lanes per element; a lane adds P / TW partials (stride TW), then an LDS tree over the TW lanes.
+// lanes per element (lane tid = sub * per_wg + element); a lane adds P / TW partials (stride TW), then an LDS tree over the TW lanes.
 template <class C>
 __global__ void __launch_bounds__(256) msm_axis_fold_kernel(const XYZZ<C>* __restrict__ part, XYZZ<C>* __restrict__ elem, MsmAxes A,
                                                             uint32_t row_blocks) {
@@ -1018,8 +1018,10 @@ __global__ void __launch_bounds__(256) msm_axis_fold_kernel(const XYZZ<C>* __res
     const uint32_t nelem = is_row ? A.nw * A.rows : A.nw * A.cols;
     const uint32_t TW = P < 16 ? P : 16;                  // lanes per element (power of two)
     const uint32_t per_wg = TL / TW;
-    const uint32_t e = (is_row ? blockIdx.x : blockIdx.x - row_blocks) * per_wg + tid / TW;
-    const uint32_t sub = tid % TW;
+    // sub-major lane order: the lanes that are still adding at tree level d are tid < d * per_wg, so whole waves drop out of the
+    // deeper levels (element-major order keeps one busy lane in every wave until the last level: 4.5 x the wave-additions)
+    const uint32_t e = (is_row ? blockIdx.x : blockIdx.x - row_blocks) * per_wg + tid % per_wg;
+    const uint32_t sub = tid / per_wg;
     const bool live = e < nelem;
     const XYZZ<C>* src = part + (is_row ? 0u : A.row_lanes) + (uint64_t)e * P;
     const uint32_t serial = P / TW;
@@ -1039,7 +1041,7 @@ __global__ void __launch_bounds__(256) msm_axis_fold_kernel(const XYZZ<C>* __res
         } else {
             const uint32_t d = TW >> (k - serial + 1);
             on = sub < d;
-            if (on) b = sh[tid + d];
+            if (on) b = sh[tid + d * per_wg];
         }
         if (on) xyzz_add(acc, b);
         if (k + 1 >= serial) {
