@@ -283,7 +283,7 @@ struct ExprOp {
 };
 constexpr uint32_t EXPR_MAX_OPS = 512, EXPR_MAX_COLS = 64, EXPR_MAX_CONSTS = 32, EXPR_STACK = 8, EXPR_WG = 128;
 
-// LDS: per-lane stack, limb-major (bank-conflict-free): stack[(slot * N + limb) * EXPR_WG + lane]
+// LDS: per-lane stack below the top (which stays in registers), limb-major (bank-conflict-free): stack[(slot * N + limb) * EXPR_WG + lane]
 // The program is read as one aligned 64-bit word per op (op | rot << 16 | arg << 32) and decoded with shifts: every lane
 // runs the same program, so the compiler turns these reads into scalar loads, and a scalar load of a field at a 2-byte
 // offset inside the struct is not something to rely on.  Operand indices are clamped against the table sizes as well:
@@ -296,57 +296,55 @@ __global__ void __launch_bounds__(EXPR_WG) expr_eval_kernel(const uint64_t* __re
     const uint32_t lane = threadIdx.x;
     const uint64_t n = 1ull << log_n, mask = n - 1;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + lane; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        // the top of the stack lives in registers (`tos`); slots 0 .. sp - 2 in LDS.  A binary operation then costs one LDS
+        // read instead of two reads and a write, a unary one none: the adds and subtractions of a gate expression (~25
+        // instructions each) were spending twice that on moving operands.  (Measured: no change in kernel time -- the 81 saturated
+        // products per row set it, two dependent VALU instructions per partial product; the column values would have to arrive in
+        // the lazy-limb radix for the cheaper product to apply.)
         uint32_t sp = 0;
+        Fe<F> tos;
+        fe_zero(tos);
         for (uint32_t k = 0; k < n_ops; k++) {
             const uint64_t w = prog[k];
             const uint32_t op = (uint32_t)(w & 0xff), arg = (uint32_t)(w >> 32);
             const int32_t rot = (int32_t)(int16_t)(uint16_t)(w >> 16);
-            Fe<F> x, y;
             if (op <= 1) {
                 if (sp >= EXPR_STACK) break;
+                if (sp >= 1) {
+                    ZK_UNROLL
+                    for (int l = 0; l < F::N; l++) stack[((sp - 1) * F::N + l) * EXPR_WG + lane] = tos.v[l];
+                }
                 if (op == 0) {
                     const uint64_t j = (i + (uint64_t)((int64_t)rot * (int64_t)rot_scale)) & mask;
-                    x = cols[arg < n_cols ? arg : 0][j];
+                    tos = cols[arg < n_cols ? arg : 0][j];
                 } else {
-                    x = consts[arg < n_consts ? arg : 0];
+                    tos = consts[arg < n_consts ? arg : 0];
                 }
-                ZK_UNROLL
-                for (int l = 0; l < F::N; l++) stack[(sp * F::N + l) * EXPR_WG + lane] = x.v[l];
                 sp++;
             } else if (op == 5 || op == 6) {
                 if (sp < 1) break;
-                ZK_UNROLL
-                for (int l = 0; l < F::N; l++) x.v[l] = stack[((sp - 1) * F::N + l) * EXPR_WG + lane];
                 if (op == 5) {
-                    fe_neg(x, x);
+                    fe_neg(tos, tos);
                 } else {
-                    y = consts[arg < n_consts ? arg : 0];
-                    fe_mul(x, x, y);
+                    const Fe<F> y = consts[arg < n_consts ? arg : 0];
+                    fe_mul(tos, tos, y);
                 }
-                ZK_UNROLL
-                for (int l = 0; l < F::N; l++) stack[((sp - 1) * F::N + l) * EXPR_WG + lane] = x.v[l];
             } else {
                 if (sp < 2) break;
+                Fe<F> x;
                 ZK_UNROLL
-                for (int l = 0; l < F::N; l++) {
-                    x.v[l] = stack[((sp - 2) * F::N + l) * EXPR_WG + lane];
-                    y.v[l] = stack[((sp - 1) * F::N + l) * EXPR_WG + lane];
-                }
+                for (int l = 0; l < F::N; l++) x.v[l] = stack[((sp - 2) * F::N + l) * EXPR_WG + lane];
                 if (op == 2)
-                    fe_add(x, x, y);
+                    fe_add(x, x, tos);
                 else if (op == 3)
-                    fe_sub(x, x, y);
+                    fe_sub(x, x, tos);
                 else
-                    fe_mul(x, x, y);
+                    fe_mul(x, x, tos);
+                tos = x;
                 sp--;
-                ZK_UNROLL
-                for (int l = 0; l < F::N; l++) stack[((sp - 1) * F::N + l) * EXPR_WG + lane] = x.v[l];
             }
         }
-        Fe<F> r;
-        ZK_UNROLL
-        for (int l = 0; l < F::N; l++) r.v[l] = stack[l * EXPR_WG + lane];
-        out[i] = r;
+        out[i] = tos;
     }
 }
 
