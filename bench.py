@@ -184,8 +184,8 @@ def rooflines(e, workload_key):
         out["msm_accumulate_kernel"] = {
             "kernel": "msm_accumulate_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-            "launches": m["msms"], "avg_launch_us": m["accumulate_kernel_ms"] / m["msms"] * 1e3,
-            "algorithmic_bytes_per_launch": m["algorithmic_bytes"] / m["msms"], "kernel_ms_total": m["accumulate_kernel_ms"],
+            "launches": m["launches"], "msms": m["msms"], "avg_launch_us": m["accumulate_kernel_ms"] / m["launches"] * 1e3,
+            "algorithmic_bytes_per_launch": m["algorithmic_bytes"] / m["launches"], "kernel_ms_total": m["accumulate_kernel_ms"],
             "valu_wave_insts_per_launch": valu,
             "note": "integer-VALU-bound by construction (SURVEY 8d): see int_mad_roofline / valu_issue_roofline"}
     if t["launches"]:
@@ -234,7 +234,7 @@ def base_line(e, value, elapsed, workload, cfg):
     return {"metric": "constraints/sec", "value": value, "unit": "constraints/s", "n_gpus": e.world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "u32 limbs (256/384-bit Montgomery integers; MSM buckets on 9 x 29 / 14 x 28-bit lazy limbs, NTT on 8 x 32)",
+            "dtype": "u32 limbs (256/384-bit Montgomery integers; MSM buckets and NTT tiles on 9 x 29 / 14 x 28-bit lazy limbs)",
             "data": "synthetic", "config": dict({"workload": workload, "parallelism": "msm-window-shard x%d + all_gather" % e.world
                                                   if e.world > 1 else "single-gpu"}, **cfg)}
 

@@ -69,7 +69,8 @@ class MsmProfile(ctypes.Structure):
 
 class MsmTotals(ctypes.Structure):
     _fields_ = [("msms", ctypes.c_uint64)] + [(k, ctypes.c_double) for k in (
-        "accumulate_kernel_ms", "accumulate_ms", "sort_ms", "reduce_ms", "host_tail_ms", "device_ms", "algorithmic_bytes")]
+        "accumulate_kernel_ms", "accumulate_ms", "sort_ms", "reduce_ms", "host_tail_ms", "device_ms", "algorithmic_bytes")] + [
+        ("launches", ctypes.c_uint64)]
 
 
 class NttTotals(ctypes.Structure):

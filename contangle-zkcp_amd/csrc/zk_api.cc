@@ -256,7 +256,8 @@ int collect_job(MsmJob& job, void* out) {
         std::lock_guard<std::mutex> lk(g.mu);
         g.prof = job.prof;
         if (!job.empty) {
-            g.totals.msms++;
+            g.totals.msms += job.batch;
+            g.totals.launches++;
             g.totals.accumulate_kernel_ms += job.prof.accumulate_kernel_ms;
             g.totals.accumulate_ms += job.prof.accumulate_ms;
             g.totals.sort_ms += job.prof.digits_ms + job.prof.hist_ms + job.prof.scatter_ms;
@@ -706,33 +707,56 @@ API int zk_msm_batch_device(zk_curve_t c, uint64_t handle, const void* d_scalars
         HIP_TRY(hipEventRecord(dc.fork_ev, (hipStream_t)stream));
         for (auto& s : dc.side) HIP_TRY(hipStreamWaitEvent(s, dc.fork_ev, 0));
     }
-    // MSM k runs on side stream k mod 2; at most ZK_MAX_JOBS - 1 in flight, collected in order
-    std::vector<MsmJob*> inflight;
-    uint32_t submitted = 0, collected = 0;
+    // Up to 4 scalar vectors go into ONE job: their windows are simply more windows of the same sort / accumulate / reduce
+    // launches (one persistent accumulate launch without a drain per MSM, the latency-bound reduction steps once per job).
+    // The bound is the (window, range) region count the sort kernels index: 4096.  Job k runs on side stream k mod 2; at most
+    // ZK_MAX_JOBS - 1 in flight, collected in order.
+    uint32_t per_job = 1;
+    {
+        int cw = 0, nwin = 0;
+        CURVE_SWITCH(c, cw = msm_pick_c(n, tu.window_bits); nwin = msm_windows<C>(cw));
+        const int nwj = (tu.w0 == 0 && tu.w1 == 0) ? nwin : tu.w1 - tu.w0;
+        const uint32_t nbk = 1u << (cw - 1), nranges = nbk > 512 ? nbk / 512 : 1;
+        const uint32_t regions = (uint32_t)(nwj > 0 ? nwj : 1) * nranges;
+        per_job = 4096 / regions;
+        if (per_job > 4) per_job = 4;
+        if (per_job < 1) per_job = 1;
+        if ((uint64_t)n * (uint64_t)(nwj > 0 ? nwj : 1) * per_job >= (1ull << 32)) per_job = 1;   // entry positions are u32
+    }
+    struct Flight {
+        MsmJob* job;
+        uint32_t first, size;
+    };
+    std::vector<Flight> inflight;
+    uint32_t submitted = 0, collected = 0, jobs = 0;
     int status = ZK_OK;
     while (collected < count && status == ZK_OK) {
         while (submitted < count && inflight.size() < (size_t)ZK_MAX_JOBS - 1 && status == ZK_OK) {
             MsmJob* job = nullptr;
+            MsmTuning tj = tu;
+            tj.batch = count - submitted < per_job ? count - submitted : per_job;
+            tj.batch_stride = stride_elems;
             std::lock_guard<std::mutex> lk(dc.mu);
             status = submit_on(dc, c, *be, (const unsigned char*)d_scalars + (size_t)submitted * stride_elems * 32, SRC_LOCAL, 0, n, mont ? 1 : 0,
-                               tu, dc.side[submitted & 1], &job);
+                               tj, dc.side[jobs & 1], &job);
             if (status == ZK_ERR_BUSY && !inflight.empty()) {   // other callers hold the remaining slots: drain ours first
                 status = ZK_OK;
                 break;
             }
             if (status == ZK_OK) {
-                inflight.push_back(job);
-                submitted++;
+                inflight.push_back({job, submitted, tj.batch});
+                submitted += tj.batch;
+                jobs++;
             }
         }
         if (status != ZK_OK || inflight.empty()) break;
-        status = collect_job(*inflight.front(), (unsigned char*)out + (size_t)collected * pbytes);
+        status = collect_job(*inflight.front().job, (unsigned char*)out + (size_t)inflight.front().first * pbytes);
+        collected += inflight.front().size;
         inflight.erase(inflight.begin());
-        collected++;
     }
-    for (MsmJob* j : inflight) {   // error path: release what is still in flight
-        std::vector<unsigned char> sink(pbytes);
-        collect_job(*j, sink.data());
+    for (auto& fl : inflight) {   // error path: release what is still in flight
+        std::vector<unsigned char> sink(pbytes * fl.size);
+        collect_job(*fl.job, sink.data());
     }
     if (status == ZK_OK && collected < count) status = ZK_ERR_BUSY;
     {

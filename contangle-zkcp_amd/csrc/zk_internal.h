@@ -77,6 +77,8 @@ struct MsmTuning {
     bool no_hot_help = false;
     bool slice_reduce = false;   // the round-1 bucket reduction (slices + multiplier) instead of row / column sums
     uint64_t base_offset = 0;
+    uint32_t batch = 1;          // internal (zk_msm_batch_device): scalar vectors summed by ONE job
+    uint64_t batch_stride = 0;   // elements between them
 };
 
 // One MSM in flight: its own device workspaces (so two jobs on two streams never share a buffer), a pinned host buffer
@@ -96,6 +98,7 @@ struct MsmJob {
     // what collect needs
     int (*finish)(MsmJob&, void* out_jac) = nullptr;
     int curve = 0, c = 0, w0 = 0, nw = 0;
+    uint32_t batch = 1;               // results this job produces (windows [b nw, (b + 1) nw) of the partial sums belong to vector b)
     uint32_t per = 0;                 // partial sums per window
     bool axes = false;                // row / column reduction: per window [row blocks | column blocks] x (weighted, plain)
     uint32_t row_blocks = 0, col_blocks = 0, log_cols = 0, log_tl = 0;

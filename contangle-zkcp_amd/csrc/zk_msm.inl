@@ -17,13 +17,18 @@ inline double now_ms() {
 // caller has had the chance to enqueue the next MSM: the GPU never waits for it.
 template <class C, class CK>
 int msm_finish_impl(MsmJob& job, void* out_jac) {
+    const size_t out_bytes = 3 * sizeof(uint32_t) * coord_words<C>();
+    double t0 = 0;
+    if (!job.empty) {
+        HIP_TRY(hipEventSynchronize(job.ev[6]));
+        t0 = now_ms();
+    }
+    for (uint32_t bt = 0; bt < job.batch; bt++) {      // one result per scalar vector of the job
     Jacobian<C> result;
     XYZZ<C> total;
     xyzz_set_inf(total);
     if (!job.empty) {
-        HIP_TRY(hipEventSynchronize(job.ev[6]));
-        const double t0 = now_ms();
-        const XYZZ<CK>* host = (const XYZZ<CK>*)job.host_partials;
+        const XYZZ<CK>* host = (const XYZZ<CK>*)job.host_partials + (size_t)bt * job.nw * job.per;
         HostXYZZ<C> htotal, hp;
         to_host<C>(htotal, total);
         auto load = [&](HostXYZZ<C>& r, size_t i) {
@@ -71,6 +76,11 @@ int msm_finish_impl(MsmJob& job, void* out_jac) {
         }
         for (int k = 0; k < job.c * job.w0; k++) xyzz_dbl(htotal);
         from_host<C>(total, htotal);
+    }
+    xyzz_to_jacobian(result, total);
+    memcpy((unsigned char*)out_jac + (size_t)bt * out_bytes, &result, out_bytes);
+    }
+    if (!job.empty) {
         job.prof.host_tail_ms = (float)(now_ms() - t0);
         hipEventElapsedTime(&job.prof.digits_ms, job.ev[0], job.ev[1]);
         hipEventElapsedTime(&job.prof.hist_ms, job.ev[1], job.ev[2]);
@@ -82,8 +92,6 @@ int msm_finish_impl(MsmJob& job, void* out_jac) {
         job.prof.total_ms += job.prof.host_tail_ms;
         job.prof.groups = 1;
     }
-    xyzz_to_jacobian(result, total);
-    memcpy(out_jac, &result, 3 * sizeof(uint32_t) * coord_words<C>());
     return ZK_OK;
 }
 
@@ -107,6 +115,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
     job.c = c;
     job.w0 = w0;
     job.nw = w1 - w0;
+    job.batch = tu.batch ? tu.batch : 1;
     job.prof.window_bits = c;
     job.prof.windows_total = nwin;
     job.prof.windows_done = w1 - w0;
@@ -118,7 +127,10 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         sh.n = (uint32_t)n;
         sh.c = c;
         sh.w0 = w0;
-        sh.nw = w1 - w0;
+        sh.nwb = w1 - w0;
+        sh.batch = job.batch;
+        sh.batch_stride = tu.batch_stride;
+        sh.nw = sh.nwb * (int)sh.batch;          // the job's windows: those of vector 0, then of vector 1, ...
         sh.nbk = 1u << (c - 1);
         sh.rb = sh.nbk < MSM_RANGE ? sh.nbk : MSM_RANGE;
         sh.nranges = sh.nbk / sh.rb;
@@ -198,7 +210,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         HIP_TRY(hipEventRecord(ev[0], st));
         // ---- sort: partition the digits by (window, bucket range), then counting-sort every region in LDS
         const unsigned dblk = sh.sblk >= 4096 ? 1024u : 256u;   // small problems: fewer lanes, cheaper barriers
-        ZK_LAUNCH((msm_digits_kernel<C>), nblocks, dblk, (size_t)nreg * 4, st, d_scalars, sh, digits, blockcnt);
+        ZK_LAUNCH((msm_digits_kernel<C>), nblocks * sh.batch, dblk, (size_t)sh.nwb * sh.nranges * 4, st, d_scalars, sh, digits, blockcnt);
         auto lanes_for = [](uint32_t items) {   // workgroup size for a scan over `items` values: a power of two in [64, 1024]
             unsigned b = 64;
             while (b < items && b < 1024) b <<= 1;
@@ -345,7 +357,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         HIP_TRY(hipEventRecord(ev[6], st));
         job.per = per;
         job.empty = false;
-        job.alg_bytes = (double)n * (sizeof(Fe<typename C::Fr>) + sizeof(Affine<C>)) * (double)(w1 - w0) / (double)nwin;
+        job.alg_bytes = (double)job.batch * (double)n * (sizeof(Fe<typename C::Fr>) + sizeof(Affine<C>)) * (double)(w1 - w0) / (double)nwin;
     }
     return ZK_OK;
 }

@@ -47,6 +47,9 @@ struct MsmShape {
     uint32_t big_thresh;  // buckets longer than this take the cooperative path
     int split_log;        // every bucket's entry list is cut into 2^split_log pieces summed by different lanes (msm_combine_sub_kernel adds them)
     uint32_t sblk;        // scalars per workgroup of the digit / stage kernels: MSM_SBLK, less for small inputs (>= 64 workgroups)
+    uint32_t batch;       // scalar vectors summed over the same bases by this job; nw = batch * nwb windows in all, window-major per vector
+    int nwb;              // windows per scalar vector
+    uint64_t batch_stride;   // elements between the scalar vectors
 };
 
 template <int N>
@@ -105,9 +108,12 @@ template <class C>
 __global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh,
                                                           uint16_t* __restrict__ digits, uint32_t* __restrict__ blockcnt) {
     using Fr = typename C::Fr;
-    ZK_DYN_SHARED(uint32_t, cnt);   // nw * nranges
-    const uint32_t nreg = (uint32_t)sh.nw * sh.nranges;
+    ZK_DYN_SHARED(uint32_t, cnt);   // nwb * nranges: the regions of this block's scalar vector
+    const uint32_t nreg = (uint32_t)sh.nwb * sh.nranges;
     const uint32_t rb_log = 31u - (uint32_t)__clz(sh.rb);
+    const uint32_t nblocks = gridDim.x / sh.batch, blk = blockIdx.x % nblocks, bt = blockIdx.x / nblocks;   // grid = blocks x vectors
+    scalars += (uint64_t)bt * sh.batch_stride;
+    digits += (uint64_t)bt * sh.nwb * sh.n;
     for (uint32_t j = threadIdx.x; j < nreg; j += blockDim.x) cnt[j] = 0;
     __syncthreads();
     // few ranges per window (small c: the later IPA rounds, small keys): the lanes of a wave mostly hit the SAME counter, and
@@ -115,7 +121,7 @@ __global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::F
     // aggregated atomic per wave and counter instead.  Trip counts are wave-uniform: no lane leaves the loops early.
     const bool agg = sh.nranges <= 8;
     for (uint32_t k = threadIdx.x; k < sh.sblk; k += blockDim.x) {
-        const uint32_t i = blockIdx.x * sh.sblk + k;
+        const uint32_t i = blk * sh.sblk + k;
         const bool valid = i < sh.n;
         Fe<Fr> x;
         fe_zero(x);
@@ -124,7 +130,7 @@ __global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::F
             if (sh.mont) fe_from_mont(x, x);
         }
         uint32_t carry = 0;
-        for (int w = 0; w < sh.w0 + sh.nw; w++) {
+        for (int w = 0; w < sh.w0 + sh.nwb; w++) {
             const uint32_t raw = bits_at<Fr::N>(x.v, w * sh.c, sh.c) + carry;
             const bool neg = raw > sh.nbk;
             const uint32_t mag = neg ? (1u << sh.c) - raw : raw;
@@ -141,7 +147,7 @@ __global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::F
         }
     }
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < nreg; j += blockDim.x) blockcnt[(uint64_t)j * gridDim.x + blockIdx.x] = cnt[j];
+    for (uint32_t j = threadIdx.x; j < nreg; j += blockDim.x) blockcnt[((uint64_t)bt * nreg + j) * nblocks + blk] = cnt[j];
 }
 
 // grid = regions: exclusive scan of the region's block counts in place; wg_total[region] = their sum

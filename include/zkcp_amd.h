@@ -115,6 +115,7 @@ typedef struct {
     uint64_t msms;
     double accumulate_kernel_ms, accumulate_ms, sort_ms, reduce_ms, host_tail_ms, device_ms;
     double algorithmic_bytes;
+    uint64_t launches;   /* accumulate-kernel launches: zk_msm_batch_device sums up to 4 scalar vectors per launch sequence */
 } zk_msm_totals;
 
 /* NTT pass-kernel timing (off by default): when enabled, every ntt_pass_kernel launch is bracketed by HIP events on its

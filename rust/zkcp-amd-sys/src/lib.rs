@@ -75,6 +75,7 @@ pub struct zk_msm_totals {
     pub host_tail_ms: f64,
     pub device_ms: f64,
     pub algorithmic_bytes: f64,
+    pub launches: u64,
 }
 #[repr(C)]
 #[derive(Default, Clone, Copy)]

@@ -437,6 +437,13 @@ def check_msm_batch(zk, cname, n, count, window_bits=0):
     got = zk.msm_batch(bases, to_device(zk, mont), montgomery=True, window_bits=window_bits)
     for i in range(count):
         assert (affine_of(zk, cname, got[i]) == exp[i]).all(), (cname, n, i, "montgomery")
+    # a window share of every vector (the sharded form): up to 4 vectors ride in one job, each keeps its own windows
+    W = zk.msm_window_count(cname, n, window_bits)
+    if W >= 2:
+        lo = zk.msm_batch(bases, to_device(zk, cols), window_bits=window_bits, windows=(0, W // 2))
+        hi = zk.msm_batch(bases, to_device(zk, cols), window_bits=window_bits, windows=(W // 2, W))
+        for i in range(count):
+            assert (affine_of(zk, cname, zk.point_add(cname, lo[i], hi[i])) == exp[i]).all(), (cname, n, i, "window shares")
     bases.free()
 
 

@@ -171,6 +171,7 @@ def test_halo2_products(zk):
 def test_halo2_ipa(zk):
     ps.check_ipa(zk, "Vesta", 4)
     ps.check_ipa(zk, "Pallas", 2)
+    ps.check_ipa(zk, "Bn254G1", 2)
 
 
 def test_halo2_expression(zk):

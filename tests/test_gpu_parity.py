@@ -492,7 +492,7 @@ def test_halo2_permutation_and_lookup_products(zk, name, k):
     ps.check_permutation_and_lookup_products(zk, name, k)
 
 
-@pytest.mark.parametrize("cname,k", [("Vesta", 6), ("Pallas", 5)])
+@pytest.mark.parametrize("cname,k", [("Vesta", 6), ("Pallas", 5), ("Bn254G1", 4), ("Bls381G1", 3)])   # the argument is halo2's (Pasta); the entry points take every curve
 def test_halo2_ipa(zk, cname, k):
     ps.check_ipa(zk, cname, k)
 
