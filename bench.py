@@ -35,7 +35,7 @@ NCOL = 13   # advice columns of the reference's halo2 circuit
 
 
 KERNEL_SOURCES = ("zk_field.h", "zk_field29.h", "zk_mul_asm.h", "zk_params.h", "zk_params29.h", "zk_curve.h", "zk_curve29.h",
-                  "zk_msm_kernels.h", "zk_ntt_kernels.h", "zk_msm.inl", "zk_ntt.inl")
+                  "zk_msm_kernels.h", "zk_ntt_kernels.h", "zk_ntt29_kernels.h", "zk_msm.inl", "zk_ntt.inl")
 
 
 def kernel_src_sha16():

@@ -138,6 +138,10 @@ void free_device(DeviceCtx& dc) {
         ws_free(s->poly_a);
         ws_free(s->poly_b);
         ws_free(s->poly_tot);
+        if (s->pinned) hipHostFree(s->pinned);
+        if (s->pinned_ev) hipEventDestroy(s->pinned_ev);
+        s->pinned = nullptr;
+        s->pinned_ev = nullptr;
     }
     dc.scratch.clear();
     for (auto& j : dc.jobs) free_job(j);
