@@ -92,9 +92,9 @@ fn repr_limbs<F: FieldExt>(x: &F) -> [u64; 4] {
 /// R mod p: what `F::one()` looks like in memory if the struct is the bare limb array
 fn montgomery_one<F: FieldExt>() -> [u64; 4] { repr_limbs(&radix::<F>()) }
 /// Montgomery limbs (x R mod p) of x, without looking at the struct
-fn limbs_of<F: FieldExt>(x: &F) -> [u64; 4] { repr_limbs(&(*x * radix::<F>())) }
+pub(crate) fn limbs_of<F: FieldExt>(x: &F) -> [u64; 4] { repr_limbs(&(*x * radix::<F>())) }
 /// the field element whose Montgomery limbs are `m`
-fn from_montgomery_limbs<F: FieldExt>(m: &[u64]) -> F {
+pub(crate) fn from_montgomery_limbs<F: FieldExt>(m: &[u64]) -> F {
     let mut wide = [0u8; 64];
     for i in 0..4 {
         wide[8 * i..8 * i + 8].copy_from_slice(&m[i].to_le_bytes());
@@ -143,7 +143,7 @@ fn srs_handle<C: CurveAffine>(curve: i32, bases: &[C]) -> u64 {
     h
 }
 /// pasta Ep / Eq are Jacobian (x, y, z); z = 0 is the identity.  `new_jacobian` checks the curve equation.
-fn curve_from_jacobian_limbs<C: CurveAffine>(j: &[u64]) -> C::Curve {
+pub(crate) fn curve_from_jacobian_limbs<C: CurveAffine>(j: &[u64]) -> C::Curve {
     use pasta_curves::arithmetic::CurveExt;
     if j[8..12].iter().all(|&w| w == 0) {
         return C::Curve::identity();

@@ -363,3 +363,54 @@ pub fn jacobian_to_ark_uncompressed(curve: c_int, jac: &[u64]) -> Vec<u8> {
     check(unsafe { zk_ark_points_encode(curve, aff.as_ptr() as _, 1, 0, out.as_mut_ptr()) }, "zk_ark_points_encode").unwrap();
     out
 }
+
+// =====================================================================================================================
+// device buffers for the *_device entry points (the library takes plain device pointers; the forks own the memory)
+// =====================================================================================================================
+#[link(name = "amdhip64")]
+extern "C" {
+    fn hipMalloc(ptr: *mut *mut c_void, bytes: usize) -> c_int;
+    fn hipFree(ptr: *mut c_void) -> c_int;
+    fn hipMemcpy(dst: *mut c_void, src: *const c_void, bytes: usize, kind: c_int) -> c_int;
+    fn hipMemset(dst: *mut c_void, value: c_int, bytes: usize) -> c_int;
+}
+const HIP_MEMCPY_HOST_TO_DEVICE: c_int = 1;
+const HIP_MEMCPY_DEVICE_TO_HOST: c_int = 2;
+
+/// `len` u64 words in HBM (a field element is 4 of them, a G1 affine point 8 or 12), freed on drop
+pub struct DeviceBuf {
+    ptr: *mut c_void,
+    len: usize,
+}
+unsafe impl Send for DeviceBuf {}
+impl DeviceBuf {
+    pub fn zeroed(len: usize) -> Self {
+        let mut ptr = std::ptr::null_mut();
+        let bytes = len.max(1) * 8;
+        assert_eq!(unsafe { hipMalloc(&mut ptr, bytes) }, 0, "hipMalloc({})", bytes);
+        assert_eq!(unsafe { hipMemset(ptr, 0, bytes) }, 0, "hipMemset");
+        DeviceBuf { ptr, len }
+    }
+    pub fn upload(words: &[u64]) -> Self {
+        let b = Self::zeroed(words.len());
+        assert_eq!(unsafe { hipMemcpy(b.ptr, words.as_ptr() as _, words.len() * 8, HIP_MEMCPY_HOST_TO_DEVICE) }, 0, "hipMemcpy H2D");
+        b
+    }
+    /// `n` copies of one field element (e.g. the Montgomery form of 1: the initial IPA weights)
+    pub fn filled(n: usize, elem: &[u64; 4]) -> Self {
+        let host: Vec<u64> = (0..n).flat_map(|_| elem.iter().copied()).collect();
+        Self::upload(&host)
+    }
+    pub fn download(&self, first_word: usize, out: &mut [u64]) {
+        assert!(first_word + out.len() <= self.len);
+        let src = unsafe { (self.ptr as *const u64).add(first_word) };
+        assert_eq!(unsafe { hipMemcpy(out.as_mut_ptr() as _, src as _, out.len() * 8, HIP_MEMCPY_DEVICE_TO_HOST) }, 0, "hipMemcpy D2H");
+    }
+    pub fn ptr(&self) -> *mut c_void { self.ptr }
+    pub fn len(&self) -> usize { self.len }
+}
+impl Drop for DeviceBuf {
+    fn drop(&mut self) {
+        unsafe { hipFree(self.ptr) };
+    }
+}
