@@ -310,6 +310,9 @@ class IpaProverVirtual:
 
     def round(self, sharded=False):
         half = self.n // 2
+        if sharded:
+            from . import dist as zkdist
+            sharded = self.m0 >= zkdist.SHARD_MIN_POINTS      # small rounds: every rank computes them whole, no collective
         if not sharded:     # the whole round in one call: scalars, inner products and both MSMs enqueued together
             nl = _plib().zk_curve_base_limbs64(self.curve)
             lr = np.zeros((2, 3 * nl), dtype=np.uint64)
@@ -319,7 +322,6 @@ class IpaProverVirtual:
             return lr[0], lr[1], v[0], v[1]
         _check(_plib().zk_ipa_virtual_scalars_device(self.field, _ptr(self.p), _ptr(self.W), self.m0, self.n, _ptr(self.S[0]), _ptr(self.S[1]),
                                                      ctypes.c_void_p(self.stream)), "zk_ipa_virtual_scalars_device")
-        from . import dist as zkdist
         L, R = zkdist.msm_batch_sharded(self.bases, self.S, montgomery=True, stream=self.stream)
         vl = inner_product(self.field, self.p[half:self.n], self.b[:half], stream=self.stream)
         vr = inner_product(self.field, self.p[:half], self.b[half:self.n], stream=self.stream)

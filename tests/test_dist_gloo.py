@@ -34,6 +34,7 @@ def _worker(rank, world, port, emu_path, q):
     zk.load(path=emu_path)
     zk.init(0)
     ok = True
+    zkdist.SHARD_MIN_POINTS = 0          # the test inputs are small: share them anyway
     for cname, n, wb in (("Vesta", 96, 6), ("Bls381G1", 48, 5)):
         pts = ps.bases_for(cname, n)
         sc = ps.scalars_for(cname, n, 31, realistic=(cname == "Vesta"))
@@ -56,6 +57,15 @@ def _worker(rank, world, port, emu_path, q):
         ok &= bool((zk.point_to_affine(cname, res[0]) == exp).all())
         ok &= bool((zk.point_to_affine(cname, res[1]) == orc.msm_ark(cname, pts2, cols[1], threads=2)).all())
         ok &= bool((zk.point_to_affine(cname, res[2]) == orc.msm_ark(cname, pts, cols[2], threads=2)).all())
+        # below SHARD_MIN_POINTS (the default) nothing is shared: every rank computes the whole sum, no collective
+        zkdist.SHARD_MIN_POINTS = 1 << 17
+        ok &= bool((zk.point_to_affine(cname, zkdist.msm_sharded(bases, sc, window_bits=wb)) == exp).all())
+        got = zkdist.msm_batch_sharded(bases, ps.to_device(zk, cols), window_bits=wb)
+        ok &= bool((zk.point_to_affine(cname, got[2]) == orc.msm_ark(cname, pts, cols[2], threads=2)).all())
+        res = zkdist.msm_many_sharded([(bases, ps.to_device(zk, sc), False), (bases2, ps.to_device(zk, cols[1]), False)], window_bits=wb)
+        ok &= bool((zk.point_to_affine(cname, res[0]) == exp).all())
+        ok &= bool((zk.point_to_affine(cname, res[1]) == orc.msm_ark(cname, pts2, cols[1], threads=2)).all())
+        zkdist.SHARD_MIN_POINTS = 0
         bases.free()
         bases2.free()
     zk.shutdown()
