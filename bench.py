@@ -404,7 +404,7 @@ def bench_halo2(e):
             ipa.round(sharded=e.world > 1)
             ipa.fold(us[j])
             if a.ipa == "collapse" and (j + 1) in collapse_at and j + 1 < k:
-                ipa.collapse()
+                ipa.collapse(sharded=e.world > 1)
         ipa.free()
         torch.cuda.synchronize()
         t5 = time.perf_counter()

@@ -1121,6 +1121,10 @@ API int zk_ipa_fold_bases_device(zk_curve_t c, void* g_aff, uint64_t half, const
     return ZK_ERR_INVALID_ARG;
 }
 API int zk_ipa_collapse_device(zk_curve_t c, uint64_t handle, const void* w, uint64_t m0, uint64_t cur, void* g_out, void* stream) {
+    return zk_ipa_collapse_range_device(c, handle, w, m0, cur, 0, cur, g_out, stream);
+}
+API int zk_ipa_collapse_range_device(zk_curve_t c, uint64_t handle, const void* w, uint64_t m0, uint64_t cur, uint64_t first, uint64_t count,
+                                     void* g_out, void* stream) {
     if (!w || !g_out || !aligned16(w) || !aligned16(g_out)) return ZK_ERR_INVALID_ARG;
     const BasesCopy* bc = nullptr;
     uint64_t base_n = 0;
@@ -1138,7 +1142,8 @@ API int zk_ipa_collapse_device(zk_curve_t c, uint64_t handle, const void* w, uin
     DeviceCtx& dc = *dcp;
     ZK_TRY(bind_device(dc));
     std::lock_guard<std::mutex> lk(dc.mu);
-    CURVE_SWITCH(c, return ipa_collapse_run<C>(dc, *bc, base_n, (const Fe<typename C::Fr>*)w, m0, cur, (Affine<C>*)g_out, (hipStream_t)stream));
+    CURVE_SWITCH(c, return ipa_collapse_run<C>(dc, *bc, base_n, (const Fe<typename C::Fr>*)w, m0, cur, first, count, (Affine<C>*)g_out,
+                                               (hipStream_t)stream));
     return ZK_ERR_INVALID_ARG;
 }
 API int zk_ipa_virtual_scalars_device(zk_field_t f, const void* p, const void* w, uint64_t m0, uint64_t cur, void* sl, void* sr, void* stream) {

@@ -547,19 +547,21 @@ int ipa_fold_bases_run(DeviceCtx& dc, Affine<C>* gens, uint64_t half, const Fe<t
     HIP_TRY(hipGetLastError());
     return ZK_OK;
 }
-// G'[i] = sum_{t < T} W_t G0[t cur + i] for i < cur (T = m0 / cur): what r = log2 T literal folds would have left in the
-// first `cur` generators (zk_msm_kernels.h, "Several IPA rounds of generator folding at once").  w_dev: the weight vector of
+// G'[i] = sum_{t < T} W_t G0[t cur + i] for first <= i < first + count <= cur (T = m0 / cur): what r = log2 T literal folds would
+// have left in generators [first, first + count) (a rank's share of the survivors, or all of them) (zk_msm_kernels.h, "Several IPA rounds of generator folding at once").  w_dev: the weight vector of
 // the fold-free rounds; only W[t cur] is read (the weights do not depend on i).
 template <class C>
 int ipa_collapse_run(DeviceCtx& dc, const BasesCopy& bc, uint64_t base_n, const Fe<typename C::Fr>* w_dev, uint64_t m0, uint64_t cur,
-                     Affine<C>* g_out, hipStream_t st) {
+                     uint64_t first, uint64_t count, Affine<C>* g_out, hipStream_t st) {
     using Fr = typename C::Fr;
     using CK = F29View<C>;
     if (cur == 0 || m0 == 0 || (m0 & (m0 - 1)) || (cur & (cur - 1)) || cur > m0 || m0 > base_n) return ZK_ERR_INVALID_ARG;
     if (m0 >= (1ull << 31) || m0 / cur > 4096 || !bc.dev29) return ZK_ERR_UNSUPPORTED;
-    const uint32_t T = (uint32_t)(m0 / cur), m = (uint32_t)cur;
+    if (first > cur || count > cur - first) return ZK_ERR_INVALID_ARG;
+    if (count == 0) return ZK_OK;
+    const uint32_t T = (uint32_t)(m0 / cur), m = (uint32_t)cur, i0 = (uint32_t)first, cnt = (uint32_t)count;
     if (T == 1) {
-        HIP_TRY(hipMemcpyAsync(g_out, bc.dev, (size_t)m * sizeof(Affine<C>), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(g_out, (const Affine<C>*)bc.dev + i0, (size_t)cnt * sizeof(Affine<C>), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         return ZK_OK;
     }
@@ -580,8 +582,8 @@ int ipa_collapse_run(DeviceCtx& dc, const BasesCopy& bc, uint64_t base_n, const 
     ZK_TRY(stream_scratch(dc, st, &ss));
     const size_t list_words = (size_t)nwin * nbk + 1 + (size_t)nwin * T;
     ZK_TRY(ws_get(ss->poly_a, (size_t)T * sizeof(Fe<Fr>) + list_words * 4 + 64));
-    ZK_TRY(ws_get(ss->poly_b, (size_t)nwin * m * sizeof(XYZZ<CK>)));
-    ZK_TRY(ws_get(ss->fb_tmp, (size_t)m * sizeof(XYZZ<C>)));
+    ZK_TRY(ws_get(ss->poly_b, (size_t)nwin * cnt * sizeof(XYZZ<CK>)));
+    ZK_TRY(ws_get(ss->fb_tmp, (size_t)cnt * sizeof(XYZZ<C>)));
     Fe<Fr>* d_w = (Fe<Fr>*)ss->poly_a.p;
     uint32_t* d_off = (uint32_t*)(d_w + T);
     uint32_t* d_ent = d_off + (size_t)nwin * nbk + 1;
@@ -626,12 +628,12 @@ int ipa_collapse_run(DeviceCtx& dc, const BasesCopy& bc, uint64_t base_n, const 
     HIP_TRY(hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_ent, ent.data(), ent.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));   // the host vectors go out of scope below
-    const uint64_t lanes = (uint64_t)nwin * m;
+    const uint64_t lanes = (uint64_t)nwin * cnt;
     ZK_LAUNCH((ipa_collapse_window_kernel<CK>), (unsigned)((lanes + 63) / 64), 64, 0, st, (const StoredAffine<CK>*)bc.dev29,
-              (const uint32_t*)d_off, (const uint32_t*)d_ent, part, m, nbk, nwin);
-    ZK_LAUNCH((ipa_collapse_horner_kernel<C>), (m + 63) / 64, 64, 0, st, (const XYZZ<CK>*)part, tmp, m, (uint32_t)c, nwin);
-    const uint64_t nl = ((uint64_t)m + FB_K - 1) / FB_K;
-    ZK_LAUNCH((xyzz_batch_to_affine_kernel<C>), (unsigned)((nl + 63) / 64), 64, 0, st, (const XYZZ<C>*)tmp, g_out, m);
+              (const uint32_t*)d_off, (const uint32_t*)d_ent, part, m, i0, cnt, nbk, nwin);
+    ZK_LAUNCH((ipa_collapse_horner_kernel<C>), (cnt + 63) / 64, 64, 0, st, (const XYZZ<CK>*)part, tmp, cnt, (uint32_t)c, nwin);
+    const uint64_t nl = ((uint64_t)cnt + FB_K - 1) / FB_K;
+    ZK_LAUNCH((xyzz_batch_to_affine_kernel<C>), (unsigned)((nl + 63) / 64), 64, 0, st, (const XYZZ<C>*)tmp, g_out, cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));   // g_out is complete on return: the caller adopts it as a bases handle next (any stream)
     return ZK_OK;

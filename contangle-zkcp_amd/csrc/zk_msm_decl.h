@@ -17,6 +17,6 @@ int fixed_base_msm_run(DeviceCtx& dc, const Affine<C>& base, const Fe<typename C
 template <class C>
 int ipa_fold_bases_run(DeviceCtx& dc, Affine<C>* g, uint64_t half, const Fe<typename C::Fr>& u_canonical, hipStream_t st);
 template <class C>
-int ipa_collapse_run(DeviceCtx& dc, const BasesCopy& bc, uint64_t base_n, const Fe<typename C::Fr>* w_dev, uint64_t m0, uint64_t cur, Affine<C>* g_out,
-                     hipStream_t st);
+int ipa_collapse_run(DeviceCtx& dc, const BasesCopy& bc, uint64_t base_n, const Fe<typename C::Fr>* w_dev, uint64_t m0, uint64_t cur, uint64_t first,
+                     uint64_t count, Affine<C>* g_out, hipStream_t st);
 }  // namespace zk

@@ -1242,9 +1242,11 @@ __global__ void __launch_bounds__(256) ipa_gather_weights_kernel(const Fe<typena
 template <class CK>
 __global__ void __launch_bounds__(64) ipa_collapse_window_kernel(const StoredAffine<CK>* __restrict__ bases, const uint32_t* __restrict__ list_off,
                                                                  const uint32_t* __restrict__ list_ent, XYZZ<CK>* __restrict__ out, uint32_t m,
-                                                                 uint32_t nbk, uint32_t nwin) {
+                                                                 uint32_t i0, uint32_t cnt, uint32_t nbk, uint32_t nwin) {
+    // outputs i0 .. i0 + cnt of the m survivors (a rank's share, or all of them); out is [window][cnt]
     const uint64_t gt = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t i = (uint32_t)(gt % m), w = (uint32_t)(gt / m);
+    const uint32_t il = (uint32_t)(gt % cnt), w = (uint32_t)(gt / cnt);
+    const uint32_t i = i0 + il;
     if (w >= nwin) return;
     XYZZ<CK> run, acc;
     xyzz_set_inf(run);
@@ -1274,7 +1276,7 @@ __global__ void __launch_bounds__(64) ipa_collapse_window_kernel(const StoredAff
                 run = X;
         }
     }
-    out[(uint64_t)w * m + i] = acc;
+    out[(uint64_t)w * cnt + il] = acc;
 }
 
 // out[i] = sum_w 2^(c w) part[w m + i]  (Horner from the top window), as a saturated-limb XYZZ point for the batched normalisation

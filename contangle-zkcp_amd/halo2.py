@@ -19,7 +19,7 @@ from . import (Bases, _check, _np64, _ptr, base_limbs, curve_id, field_id, field
 
 PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo2_permutation_product_device",
                   "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
-                  "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device", "zk_ipa_round_device"]
+                  "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device", "zk_ipa_collapse_range_device", "zk_ipa_round_device"]
 
 
 def best_multiexp(coeffs, bases):
@@ -153,6 +153,7 @@ def _plib():
     lib.zk_ipa_virtual_scalars_device.argtypes = [i32, vp, vp, u64, u64, vp, vp, vp]
     lib.zk_ipa_update_weights_device.argtypes = [i32, vp, u64, u64, vp, vp]
     lib.zk_ipa_collapse_device.argtypes = [i32, u64, vp, u64, u64, vp, vp]
+    lib.zk_ipa_collapse_range_device.argtypes = [i32, u64, vp, u64, u64, u64, u64, vp, vp]
     lib.zk_ipa_round_device.argtypes = [i32, u64, vp, vp, vp, u64, u64, vp, vp, vp, vp]
     lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     return lib
@@ -336,12 +337,42 @@ class IpaProverVirtual:
                "zk_ipa_update_weights_device")
         self.n = half
 
-    def collapse(self):
-        """G' of the rounds done so far, as a device buffer [n, 2 * limbs] of affine points; the later rounds run over it"""
+    def collapse(self, sharded=False):
+        """G' of the rounds done so far, as a device buffer [n, 2 * limbs] of affine points; the later rounds run over it.
+        sharded: the ranks of a torch.distributed job (all holding the same state) compute n / world survivors each and
+        exchange them with one all_gather."""
         nl = _plib().zk_curve_base_limbs64(self.curve)
         g = self.new_buffer((self.n, 2 * nl))
-        _check(_plib().zk_ipa_collapse_device(self.curve, self.bases.handle, _ptr(self.W), self.m0, self.n, _ptr(g), ctypes.c_void_p(self.stream)),
-               "zk_ipa_collapse_device")
+        world, rank = 1, 0
+        if sharded:
+            import torch.distributed as tdist
+            if tdist.is_initialized():
+                world, rank = tdist.get_world_size(), tdist.get_rank()
+        if world > 1 and self.n % world == 0 and self.n // world >= 64:
+            import torch
+            share = self.n // world
+            mine = g[rank * share:(rank + 1) * share]
+            _check(_plib().zk_ipa_collapse_range_device(self.curve, self.bases.handle, _ptr(self.W), self.m0, self.n, rank * share, share,
+                                                        _ptr(mine), ctypes.c_void_p(self.stream)), "zk_ipa_collapse_range_device")
+            # (the call above synchronises the stream: `mine` is complete)
+            if isinstance(g, np.ndarray):                                   # the CPU test emulator: "device" memory is host memory
+                t = torch.from_numpy(np.ascontiguousarray(mine).view(np.int64))
+                outs = [torch.empty_like(t) for _ in range(world)]
+                tdist.all_gather(outs, t)
+                for r, o in enumerate(outs):
+                    g[r * share:(r + 1) * share] = o.numpy().view(np.uint64).reshape(share, 2 * nl)
+            elif tdist.get_backend() == "nccl":                             # RCCL over xGMI, device to device, in place
+                tdist.all_gather_into_tensor(g.view(-1), mine.reshape(-1).clone())
+                torch.cuda.synchronize()                                    # g is adopted as a bases handle next (another stream)
+            else:                                                           # gloo rehearsal on a GPU box: staged through the host
+                t = mine.cpu()
+                outs = [torch.empty_like(t) for _ in range(world)]
+                tdist.all_gather(outs, t)
+                g.copy_(torch.cat(outs).to(g.device))
+                torch.cuda.synchronize()
+        else:
+            _check(_plib().zk_ipa_collapse_device(self.curve, self.bases.handle, _ptr(self.W), self.m0, self.n, _ptr(g), ctypes.c_void_p(self.stream)),
+                   "zk_ipa_collapse_device")
         if self._own_bases is not None:
             self._own_bases.free()
         self._g = g                                   # adopted, not copied: kept alive here

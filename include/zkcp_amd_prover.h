@@ -154,6 +154,10 @@ int zk_ipa_round_device(zk_curve_t c, uint64_t bases_handle, const void *p_dev, 
  * Synchronises hip_stream: g_out is complete on return. */
 int zk_ipa_collapse_device(zk_curve_t c, uint64_t bases_handle, const void *w_dev, uint64_t m0, uint64_t cur, void *g_out_affine_dev,
                            void *hip_stream);
+/* ... outputs [first, first + count) only, written to g_out_range_dev[0 .. count): a rank's share when several GPUs split the step
+ * (the shares are exchanged with one all_gather: contangle-zkcp_amd/halo2.py IpaProverVirtual.collapse) */
+int zk_ipa_collapse_range_device(zk_curve_t c, uint64_t bases_handle, const void *w_dev, uint64_t m0, uint64_t cur, uint64_t first,
+                                 uint64_t count, void *g_out_range_dev, void *hip_stream);
 
 /* The quotient numerator: one stack program evaluated at every row of the extended domain (plonk/prover.rs: each gate's
  * Expression over advice / fixed / instance columns with rotations, folded with y).  A rotation by r rows is a shift of

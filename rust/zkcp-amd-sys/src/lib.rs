@@ -235,6 +235,8 @@ extern "C" {
     pub fn zk_ipa_virtual_scalars_device(f: c_int, p_dev: *const c_void, w_dev: *const c_void, m0: u64, cur: u64, sl_dev: *mut c_void,
                                          sr_dev: *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_ipa_update_weights_device(f: c_int, w_dev: *mut c_void, m0: u64, bit: u64, u_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn zk_ipa_collapse_range_device(c: c_int, bases_handle: u64, w_dev: *const c_void, m0: u64, cur: u64, first: u64, count: u64,
+                                        g_out_range_dev: *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_ipa_round_device(c: c_int, bases_handle: u64, p_dev: *const c_void, b_dev: *const c_void, w_dev: *const c_void, m0: u64, cur: u64,
                                s_dev: *mut c_void, lr_out_host: *mut c_void, v_out_mont_host: *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_ipa_collapse_device(c: c_int, bases_handle: u64, w_dev: *const c_void, m0: u64, cur: u64, g_out_affine_dev: *mut c_void,

@@ -68,6 +68,26 @@ def _worker(rank, world, port, emu_path, q):
         zkdist.SHARD_MIN_POINTS = 0
         bases.free()
         bases2.free()
+    # the IPA's one-step generator collapse, every rank computing its share of the survivors + one all_gather
+    from oracle import pyref
+    cname, k = "Vesta", 9
+    sf = pyref.CURVES[cname][1]
+    n = 1 << k
+    gens = ps.bases_for(cname, n, seed=31)
+    srs = zk.Bases(cname, gens)
+    new_buffer = lambda shape: np.zeros(shape, dtype=np.uint64)
+    res = []
+    for sharded in (False, True):
+        vipa = zk.halo2.IpaProverVirtual(cname, ps.rand_field(sf, n, 5).copy(), ps.rand_field(sf, n, 6).copy(), srs, new_buffer)
+        for j in range(2):
+            vipa.round()
+            vipa.fold(ps.rand_field(sf, 1, 40 + j)[0])
+        res.append(vipa.collapse(sharded=sharded).copy())
+        L, R, vl, vr = vipa.round()                     # ... and the next round runs over the gathered generators
+        res.append(np.concatenate([L, R]))
+        vipa.free()
+    ok &= bool((res[0] == res[2]).all() and (res[1] == res[3]).all())
+    srs.free()
     zk.shutdown()
     dist.barrier()
     dist.destroy_process_group()
