@@ -88,6 +88,9 @@ def setup():
                          "(zk_ipa_collapse_device) and continues over them; 'fold' collapses the generator vector every round as upstream "
                          "does (one scalar multiplication per surviving point)")
     ap.add_argument("--ipa-collapse-after", default="6", help="round count(s) after which the generators are materialised, e.g. 6 or 6,10")
+    ap.add_argument("--precomputed", action="store_true",
+                    help="single-GPU A/B: the MSMs use ONE bucket set over a table of window multiples of the bases (zk_bases_precompute, 16 x the "
+                         "key in HBM) instead of one bucket set per window")
     ap.add_argument("--ntt-limbs", type=int, default=0, choices=[0, 32], help="0: lazy 29-bit limbs inside the NTT tiles (default); 32: saturated words (A/B)")
     args = ap.parse_args()
 
@@ -339,7 +342,14 @@ def bench_halo2(e):
 
     collapse_at = {int(x) for x in str(a.ipa_collapse_after).split(",") if x.strip()}
 
+    pre = a.precomputed and e.world == 1
+    if pre:
+        g_lagrange.precompute(a.window_bits)
+        g_coeff.precompute(a.window_bits)
+
     def commit_batch(bases, cols):
+        if pre:
+            return zk.msm_batch(bases, cols, montgomery=True, window_bits=a.window_bits, stream=e.st, precomputed=True)
         if a.serial:
             return [e.zkdist.msm_sharded(bases, cols[c], montgomery=True, window_bits=a.window_bits, stream=e.st) for c in range(cols.shape[0])]
         return e.zkdist.msm_batch_sharded(bases, cols, montgomery=True, window_bits=a.window_bits, stream=e.st)
@@ -510,12 +520,19 @@ def bench_column(e):
     main = torch.cuda.current_stream()
     side = main if a.serial else torch.cuda.Stream()
     result = {}
+    if a.precomputed and e.world == 1:
+        t0 = time.perf_counter()
+        bases.precompute(a.window_bits)
+        sys.stderr.write("zk_bases_precompute: %.1f ms\n" % ((time.perf_counter() - t0) * 1e3))
 
     def step(i, timed_):
         if i % e.world == e.rank:
             side.wait_stream(main)
             zk.ntt(sfield, d_a, omega, stream=side.cuda_stream)
-        result["msm"] = e.zkdist.msm_sharded(bases, d_sc, window_bits=a.window_bits, stream=e.st)
+        if a.precomputed and e.world == 1:
+            result["msm"] = zk.msm(bases, d_sc, window_bits=a.window_bits, stream=e.st, precomputed=True)
+        else:
+            result["msm"] = e.zkdist.msm_sharded(bases, d_sc, window_bits=a.window_bits, stream=e.st)
         main.wait_stream(side)
 
     elapsed = timed(e, step)

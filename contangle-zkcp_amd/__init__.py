@@ -33,7 +33,7 @@ EXPORTS = [
     "zk_point_add", "zk_point_to_affine", "zk_fixed_base_mul_device", "zk_vec_op_device", "zk_groth16_witness_map_device",
     "zk_fixed_base_msm_device", "zk_ntt_extend_device", "zk_init_devices", "zk_device_count", "zk_msm_submit", "zk_msm_collect",
     "zk_msm_batch_device", "zk_ntt_configure", "zk_msm_profile_totals", "zk_ntt_profile_enable", "zk_ntt_profile_read",
-    "zk_field_modulus", "zk_vec_scale_periodic_device", "zk_bases_refresh",
+    "zk_field_modulus", "zk_vec_scale_periodic_device", "zk_bases_refresh", "zk_bases_precompute",
 ]
 
 
@@ -53,6 +53,7 @@ class MsmOpts(ctypes.Structure):
 
 MSM_FLAG_NO_HOT_HELP = 1
 MSM_FLAG_SLICE_REDUCE = 2
+MSM_FLAG_PRECOMPUTED = 4
 
 
 class NttOpts(ctypes.Structure):
@@ -97,6 +98,7 @@ def load(path=None):
     lib.zk_bases_adopt_device.argtypes = [i32, vp, u64, ctypes.POINTER(u64)]
     lib.zk_bases_free.argtypes = [u64]
     lib.zk_bases_refresh.argtypes = [u64, u64, u64, vp]
+    lib.zk_bases_precompute.argtypes = [u64, i32]
     lib.zk_msm.argtypes = [i32, u64, vp, u64, i32, ctypes.POINTER(MsmOpts), vp]
     lib.zk_msm_device.argtypes = [i32, u64, vp, u64, i32, ctypes.POINTER(MsmOpts), vp, vp]
     lib.zk_msm_last_profile.argtypes = [ctypes.POINTER(MsmProfile)]
@@ -267,6 +269,10 @@ class Bases:
             _check(load().zk_bases_upload(self.curve, _ptr(pts), self.n, ctypes.byref(h)), "zk_bases_upload")
         self.handle = h.value
 
+    def precompute(self, window_bits=0):
+        """build the table of window multiples for msm(..., precomputed=True)"""
+        _check(load().zk_bases_precompute(self.handle, window_bits), "zk_bases_precompute")
+
     def refresh(self, offset, count, stream=0):
         """points [offset, offset + count) of the adopted device buffer were rewritten on `stream`: update the derived copies"""
         _check(load().zk_bases_refresh(self.handle, offset, count, ctypes.c_void_p(stream)), "zk_bases_refresh")
@@ -284,7 +290,7 @@ class Bases:
 
 
 def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len=0, big_threshold=0, waves_per_simd=0,
-             no_hot_help=False, base_offset=0, slice_reduce=False):
+             no_hot_help=False, base_offset=0, slice_reduce=False, precomputed=False):
     o = MsmOpts()
     o.window_bits = window_bits
     if windows is not None:
@@ -294,7 +300,8 @@ def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len
     o.slice_len = slice_len
     o.big_threshold = big_threshold
     o.waves_per_simd = waves_per_simd
-    o.flags = (MSM_FLAG_NO_HOT_HELP if no_hot_help else 0) | (MSM_FLAG_SLICE_REDUCE if slice_reduce else 0)
+    o.flags = ((MSM_FLAG_NO_HOT_HELP if no_hot_help else 0) | (MSM_FLAG_SLICE_REDUCE if slice_reduce else 0)
+               | (MSM_FLAG_PRECOMPUTED if precomputed else 0))
     o.base_offset = base_offset
     return o
 

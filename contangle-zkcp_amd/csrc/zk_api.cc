@@ -105,6 +105,7 @@ MsmTuning tuning_from(const zk_msm_opts* o) {
     t.waves = o->waves_per_simd;
     t.no_hot_help = (o->flags & ZK_MSM_FLAG_NO_HOT_HELP) != 0;
     t.slice_reduce = (o->flags & ZK_MSM_FLAG_SLICE_REDUCE) != 0;
+    t.precomputed = (o->flags & ZK_MSM_FLAG_PRECOMPUTED) != 0;
     t.base_offset = o->base_offset > 0 ? (uint64_t)o->base_offset : 0;
     return t;
 }
@@ -452,6 +453,7 @@ API int zk_shutdown(void) {
             hipDeviceSynchronize();
             if (kv.second.per_dev[d].owned) hipFree(kv.second.per_dev[d].dev);
             if (kv.second.per_dev[d].dev29) hipFree(kv.second.per_dev[d].dev29);
+            if (kv.second.per_dev[d].pre) hipFree(kv.second.per_dev[d].pre);
         }
     g.bases.clear();
     g.tickets.clear();
@@ -585,12 +587,29 @@ API int zk_bases_free(uint64_t handle) {
         if (bc.owned || bc.dev29) hipDeviceSynchronize();
         if (bc.owned) hipFree(bc.dev);
         if (bc.dev29) hipFree(bc.dev29);
+        if (bc.pre) hipFree(bc.pre);
     }
     hipSetDevice(g.devs[0]->device);
     g.bases.erase(it);
     return ZK_OK;
 }
 
+API int zk_bases_precompute(uint64_t handle, int window_bits) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    ZK_TRY(require_init());
+    auto it = g.bases.find(handle);
+    if (it == g.bases.end()) return ZK_ERR_BAD_HANDLE;
+    BasesEntry& be = it->second;
+    const zk_curve_t c = (zk_curve_t)be.curve;
+    const int cw = msm_pick_c(be.n, window_bits);
+    for (size_t d = 0; d < be.per_dev.size(); d++) {
+        ZK_TRY(bind_device(*g.devs[d]));
+        int st = ZK_ERR_INVALID_ARG;
+        CURVE_SWITCH(c, st = bases_precompute_run<C>(be.per_dev[d], be.n, cw));
+        ZK_TRY(st);
+    }
+    return ZK_OK;
+}
 API int zk_bases_refresh(uint64_t handle, uint64_t offset, uint64_t count, void* stream) {
     std::lock_guard<std::mutex> lk(g.mu);
     ZK_TRY(require_init());

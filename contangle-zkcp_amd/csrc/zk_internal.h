@@ -44,6 +44,8 @@ struct BasesCopy {
     void* dev = nullptr;     // affine points as uploaded (8 / 12 x u32 Montgomery words per coordinate)
     void* dev29 = nullptr;   // the same points in the lazy-limb view (zk_curve29.h), built once at upload
     bool owned = false;
+    void* pre = nullptr;     // optional (zk_bases_precompute): [2^(c w)] P_i for every window w, lazy-limb view, window-major
+    int pre_c = 0, pre_w = 0;
 };
 struct BasesEntry {
     int curve;
@@ -76,6 +78,7 @@ struct MsmTuning {
     int waves = 0;
     bool no_hot_help = false;
     bool slice_reduce = false;   // the round-1 bucket reduction (slices + multiplier) instead of row / column sums
+    bool precomputed = false;    // ONE bucket set over the handle's precomputed window multiples (ZK_MSM_FLAG_PRECOMPUTED)
     uint64_t base_offset = 0;
     uint32_t batch = 1;          // internal (zk_msm_batch_device): scalar vectors summed by ONE job
     uint64_t batch_stride = 0;   // elements between them

@@ -135,6 +135,27 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         sh.rb = sh.nbk < MSM_RANGE ? sh.nbk : MSM_RANGE;
         sh.nranges = sh.nbk / sh.rb;
         sh.mont = mont;
+        sh.pre_n = 0;
+        sh.pre_w = 0;
+        const bool pre = tu.precomputed;
+        const uint64_t n_real = n;
+        if (pre) {
+            // ONE bucket set over the table [2^(c w)] P_i: the job is an MSM over nwin * n table entries with c-bit "scalars" and a
+            // single window; finer ranges keep a region at the size the LDS sort handles (nwin * n / nranges entries)
+            if (w0 != 0 || w1 != nwin || n * (uint64_t)nwin >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
+            sh.pre_n = (uint32_t)n;
+            sh.pre_w = (uint32_t)nwin;
+            n = n * (uint64_t)nwin;
+            sh.n = (uint32_t)n;
+            sh.w0 = 0;
+            sh.nwb = 1;
+            sh.nw = (int)sh.batch;
+            uint32_t rb = sh.nbk < MSM_RANGE ? sh.nbk : MSM_RANGE;
+            while (rb > 8 && sh.nbk / rb < 1024 && (n / (sh.nbk / rb)) > 20000) rb >>= 1;
+            sh.rb = rb;
+            sh.nranges = sh.nbk / sh.rb;
+            job.nw = 1;
+        }
         {   // oversize threshold: 2x the mean bucket length + 64 (uniform 2^20 / c=16: mean 32, max ~70 -> none)
             const uint64_t mean = n / sh.nbk;
             sh.big_thresh = tu.big_thresh ? tu.big_thresh : (uint32_t)(2 * mean + 64);
@@ -153,6 +174,10 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
             int sl = 0;
             if (items < 8 * lanes && (n >> 1) / sh.nbk >= 8) sl = 1;
             if (items < lanes && (n >> 2) / sh.nbk >= 8) sl = 2;
+            if (pre) {                 // ~nwin * n / nbk entries per bucket: pieces of ~32
+                sl = 0;
+                while (sl < 4 && ((n >> (sl + 1)) / sh.nbk) >= 24) sl++;
+            }
             if (tu.split_log >= 0) sl = tu.split_log > 4 ? 4 : tu.split_log;
             sh.split_log = sl;
         }
@@ -162,9 +187,12 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         // keys) would leave all of its digit extraction to a handful of workgroups (72 us for 2^12 scalars in one), so it gets
         // blocks as small as 256 scalars, enough for >= 64 workgroups
         sh.sblk = MSM_SBLK;
-        while (sh.sblk > 256 && (n + sh.sblk - 1) / sh.sblk < 64) sh.sblk >>= 1;
-        const uint32_t nblocks = (uint32_t)((n + sh.sblk - 1) / sh.sblk);
-        if (nreg > 4096 || sh.nranges > 64) return ZK_ERR_UNSUPPORTED;         // LDS tables of those kernels (c <= 16: <= 1024, 64)
+        while (sh.sblk > 256 && (n_real + sh.sblk - 1) / sh.sblk < 64) sh.sblk >>= 1;
+        // precomputed form: the stage kernel's blocks are the (window, scalar block) pairs: the table must tile into whole blocks
+        if (pre && n_real % sh.sblk != 0) return ZK_ERR_UNSUPPORTED;
+        const uint32_t nblocks_real = (uint32_t)((n_real + sh.sblk - 1) / sh.sblk);
+        const uint32_t nblocks = pre ? nblocks_real * sh.pre_w : nblocks_real;
+        if (nreg > 4096 || sh.nranges > (pre ? 1024u : 64u)) return ZK_ERR_UNSUPPORTED;   // LDS tables of those kernels (c <= 16: <= 1024, 64)
         if ((uint64_t)n * (uint64_t)nw_all >= (1ull << 32)) return ZK_ERR_UNSUPPORTED;   // entry positions are u32 (2^27 points x 16 windows fit)
         // counts | offs | order | wg_total | region_base
         ZK_TRY(ws_get(job.counts, ((size_t)nbuckets * 3 + 2 * (size_t)nreg) * 4));
@@ -210,7 +238,10 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         HIP_TRY(hipEventRecord(ev[0], st));
         // ---- sort: partition the digits by (window, bucket range), then counting-sort every region in LDS
         const unsigned dblk = sh.sblk >= 4096 ? 1024u : 256u;   // small problems: fewer lanes, cheaper barriers
-        ZK_LAUNCH((msm_digits_kernel<C>), nblocks * sh.batch, dblk, (size_t)sh.nwb * sh.nranges * 4, st, d_scalars, sh, digits, blockcnt);
+        if (pre)
+            ZK_LAUNCH((msm_digits_pre_kernel<C>), nblocks_real * sh.batch, dblk, (size_t)sh.nranges * 4, st, d_scalars, sh, digits, blockcnt);
+        else
+            ZK_LAUNCH((msm_digits_kernel<C>), nblocks * sh.batch, dblk, (size_t)sh.nwb * sh.nranges * 4, st, d_scalars, sh, digits, blockcnt);
         auto lanes_for = [](uint32_t items) {   // workgroup size for a scan over `items` values: a power of two in [64, 1024]
             unsigned b = 64;
             while (b < items && b < 1024) b <<= 1;
@@ -357,7 +388,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         HIP_TRY(hipEventRecord(ev[6], st));
         job.per = per;
         job.empty = false;
-        job.alg_bytes = (double)job.batch * (double)n * (sizeof(Fe<typename C::Fr>) + sizeof(Affine<C>)) * (double)(w1 - w0) / (double)nwin;
+        job.alg_bytes = (double)job.batch * (double)n_real * (sizeof(Fe<typename C::Fr>) + sizeof(Affine<C>)) * (double)(w1 - w0) / (double)nwin;
     }
     return ZK_OK;
 }
@@ -387,6 +418,30 @@ int bases_prepare_run(BasesCopy& bc, uint64_t n) {
     return ZK_OK;
 }
 
+// the table of window multiples for the one-bucket-set form (zk_bases_precompute): nwin * n packed lazy-limb points
+template <class C>
+int bases_precompute_run(BasesCopy& bc, uint64_t n, int c) {
+    if constexpr (has_f29<C>()) {
+        const int nwin = msm_windows<C>(c);
+        if (n == 0 || n * (uint64_t)nwin >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
+        if (bc.pre) hipFree(bc.pre);
+        bc.pre = nullptr;
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, sizeof(StoredAffine<F29View<C>>) * n * nwin));
+        ZK_LAUNCH((bases_precompute_kernel<C>), (unsigned)((n + 63) / 64), 64, 0, (hipStream_t)0, (const Affine<C>*)bc.dev,
+                  (StoredAffine<F29View<C>>*)d, (uint32_t)n, (uint32_t)c, (uint32_t)nwin);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess) {
+            hipFree(d);
+            return ZK_ERR_HIP;
+        }
+        bc.pre = d;
+        bc.pre_c = c;
+        bc.pre_w = nwin;
+        return ZK_OK;
+    }
+    return ZK_ERR_UNSUPPORTED;
+}
+
 template <class C>
 int bases_refresh_run(const BasesCopy& bc, uint64_t offset, uint64_t count, hipStream_t st) {
     if constexpr (has_f29<C>()) {
@@ -402,6 +457,11 @@ int bases_refresh_run(const BasesCopy& bc, uint64_t offset, uint64_t count, hipS
 template <class C>
 int msm_enqueue(MsmJob& job, const BasesCopy& bc, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
     if constexpr (has_f29<C>()) {
+        if (tu.precomputed) {
+            if (!bc.pre || tu.base_offset != 0 || bc.pre_c != msm_pick_c(n, tu.window_bits) || bc.pre_w != msm_windows<C>(bc.pre_c))
+                return ZK_ERR_INVALID_ARG;
+            return msm_enqueue_impl<C, F29View<C>>(job, (const StoredAffine<F29View<C>>*)bc.pre, d_scalars, n, mont, tu);
+        }
         if (bc.dev29 && tu.limb_bits != 32)
             return msm_enqueue_impl<C, F29View<C>>(job, (const StoredAffine<F29View<C>>*)bc.dev29 + tu.base_offset, d_scalars, n, mont, tu);
     }

@@ -8,6 +8,8 @@ int msm_enqueue(MsmJob& job, const BasesCopy& bc, const Fe<typename C::Fr>* d_sc
 template <class C>
 int bases_prepare_run(BasesCopy& bc, uint64_t n);   // build the resident lazy-limb copy
 template <class C>
+int bases_precompute_run(BasesCopy& bc, uint64_t n, int c);   // window multiples for ZK_MSM_FLAG_PRECOMPUTED
+template <class C>
 int bases_refresh_run(const BasesCopy& bc, uint64_t offset, uint64_t count, hipStream_t st);   // re-derive it for a rewritten range
 template <class C>
 int fixed_base_run(const Fe<typename C::Fr>* d_scalars, uint64_t n, Affine<C>* d_out, hipStream_t st);

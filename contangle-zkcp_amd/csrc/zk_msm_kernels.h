@@ -50,6 +50,8 @@ struct MsmShape {
     uint32_t batch;       // scalar vectors summed over the same bases by this job; nw = batch * nwb windows in all, window-major per vector
     int nwb;              // windows per scalar vector
     uint64_t batch_stride;   // elements between the scalar vectors
+    uint32_t pre_n;       // precomputed-table form (ZK_MSM_FLAG_PRECOMPUTED): the real point count; n = pre_w * pre_n table entries,
+    uint32_t pre_w;       // ONE bucket set (nwb = 1): entry w * pre_n + i = the digit of scalar i in window w, point [2^(c w)] P_i
 };
 
 template <int N>
@@ -148,6 +150,55 @@ __global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::F
     }
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < nreg; j += blockDim.x) blockcnt[((uint64_t)bt * nreg + j) * nblocks + blk] = cnt[j];
+}
+
+// The precomputed-table form of the digit kernel: the same digit array (window-major = the entry order of the table
+// [2^(c w)] P_i), but ONE bucket set -- a digit's region is its bucket range alone -- and the "blocks" of the later kernels are
+// the (window, scalar block) pairs: block index w * nblocks + blk.  Pass 1 writes the digits, pass 2 counts every window's
+// digits per range from the block's own writes.
+template <class C>
+__global__ void __launch_bounds__(1024) msm_digits_pre_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh,
+                                                              uint16_t* __restrict__ digits, uint32_t* __restrict__ blockcnt) {
+    using Fr = typename C::Fr;
+    ZK_DYN_SHARED(uint32_t, cnt);   // nranges
+    const uint32_t R = sh.nranges;
+    const uint32_t rb_log = 31u - (uint32_t)__clz(sh.rb);
+    const uint32_t nblocks = gridDim.x / sh.batch, blk = blockIdx.x % nblocks, bt = blockIdx.x / nblocks;
+    scalars += (uint64_t)bt * sh.batch_stride;
+    digits += (uint64_t)bt * sh.n;
+    for (uint32_t k = threadIdx.x; k < sh.sblk; k += blockDim.x) {
+        const uint32_t i = blk * sh.sblk + k;
+        if (i < sh.pre_n) {
+            Fe<Fr> x = scalars[i];
+            if (sh.mont) fe_from_mont(x, x);
+            uint32_t carry = 0;
+            for (uint32_t w = 0; w < sh.pre_w; w++) {
+                const uint32_t raw = bits_at<Fr::N>(x.v, (int)(w * sh.c), sh.c) + carry;
+                const bool neg = raw > sh.nbk;
+                const uint32_t mag = neg ? (1u << sh.c) - raw : raw;
+                carry = neg ? 1u : 0u;
+                digits[(uint64_t)w * sh.pre_n + i] = (uint16_t)(neg ? 0x10000u - mag : mag);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nblocks_all = nblocks * sh.pre_w;
+    for (uint32_t w = 0; w < sh.pre_w; w++) {
+        for (uint32_t j = threadIdx.x; j < R; j += blockDim.x) cnt[j] = 0;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < sh.sblk; k += blockDim.x) {
+            const uint32_t i = blk * sh.sblk + k;
+            if (i < sh.pre_n) {
+                bool neg;
+                const uint32_t mag = digit_mag(digits[(uint64_t)w * sh.pre_n + i], neg);
+                if (mag != 0) atomicAdd(&cnt[(mag - 1) >> rb_log], 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < R; j += blockDim.x)
+            blockcnt[((uint64_t)bt * R + j) * nblocks_all + (w * nblocks + blk)] = cnt[j];
+        __syncthreads();
+    }
 }
 
 // grid = regions: exclusive scan of the region's block counts in place; wg_total[region] = their sum
@@ -1150,6 +1201,31 @@ __global__ void __launch_bounds__(256) bases_to29_kernel(const Affine<C>* __rest
     pack_base(r, q);
     out[i] = r;
 }
+
+// table[w n + i] = [2^(c w)] P_i in the stored form of the bucket kernels (packed lazy limbs), w < W: c doublings from the
+// previous window's affine point, normalised again (one inversion per entry: a one-time cost per resident key)
+template <class C>
+__global__ void __launch_bounds__(64) bases_precompute_kernel(const Affine<C>* __restrict__ in, StoredAffine<F29View<C>>* __restrict__ table,
+                                                              uint32_t n, uint32_t c, uint32_t W) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<C> p = in[i];
+    for (uint32_t w = 0; w < W; w++) {
+        if (w > 0 && !aff_is_inf(p)) {
+            XYZZ<C> acc;
+            xyzz_set_inf(acc);
+            xyzz_add_mixed(acc, p);
+            for (uint32_t k = 0; k < c; k++) xyzz_dbl(acc);
+            xyzz_to_affine(p, acc);
+        }
+        Affine<F29View<C>> q;
+        aff29_from_std(q, p);
+        Affine<C> r;
+        pack_base(r, q);
+        table[(uint64_t)w * n + i] = r;
+    }
+}
+
 
 // out[i] = [k_i] G in affine form (k canonical).  Used to build seeded test / bench bases
 // (P_i = [k_i]G) and as the building block of fixed-base setup work.

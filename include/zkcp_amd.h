@@ -88,6 +88,8 @@ typedef struct {
 } zk_msm_opts;
 #define ZK_MSM_FLAG_NO_HOT_HELP 1   /* skewed witnesses: leave hot regions to their own sort workgroup */
 #define ZK_MSM_FLAG_SLICE_REDUCE 2  /* bucket reduction by slices + multiplier (round 1) instead of row / column sums: A/B */
+#define ZK_MSM_FLAG_PRECOMPUTED 4   /* ONE bucket set over the handle's table of window multiples (zk_bases_precompute first): no per-window
+                                     * reduction, no host Horner; whole MSMs over the whole handle only */
 
 /* NTT plan knobs (process-wide, zk_ntt_configure).  Zero-initialise for defaults. */
 typedef struct {
@@ -152,6 +154,9 @@ int zk_bases_free(uint64_t handle);
  * derived copies (the lazy-limb form; the peers' copies on a multi-device process) up to date, ordered after that stream's
  * work.  halo2's IPA folds its generator vector in place every round (zk_ipa_fold_bases_device). */
 int zk_bases_refresh(uint64_t handle, uint64_t offset, uint64_t count, void *hip_stream);
+/* [2^(c w)] P_i for every window w of the MSM plan at the handle's size (16 x the points at 2^20: 1 GiB for a G1 key), for
+ * ZK_MSM_FLAG_PRECOMPUTED.  One-time cost per resident key (one inversion per table entry). */
+int zk_bases_precompute(uint64_t handle, int window_bits);
 
 /* ---- MSM: out = sum_i scalars[i] * bases[i], i < n <= bases length ----
  * scalars: n x 4 u64.  scalars_are_montgomery = 0 for ark-ec (canonical BigInt from into_repr()),

@@ -153,6 +153,7 @@ extern "C" {
     pub fn zk_bases_upload(c: c_int, affine_xy_mont_host: *const c_void, n: u64, handle_out: *mut u64) -> c_int;
     pub fn zk_bases_adopt_device(c: c_int, affine_xy_mont_dev: *const c_void, n: u64, handle_out: *mut u64) -> c_int;
     pub fn zk_bases_free(handle: u64) -> c_int;
+    pub fn zk_bases_precompute(handle: u64, window_bits: c_int) -> c_int;
     pub fn zk_bases_refresh(handle: u64, offset: u64, count: u64, hip_stream: *mut c_void) -> c_int;
     pub fn zk_msm(c: c_int, bases_handle: u64, scalars_host: *const c_void, n: u64, scalars_are_montgomery: c_int,
                   opts: *const zk_msm_opts, out_jacobian_host: *mut c_void) -> c_int;

@@ -296,6 +296,27 @@ def check_msm_slice_lengths(zk, cname, n, window_bits):
     bases.free()
 
 
+def check_msm_precomputed(zk, cname, n, window_bits, seed=37, realistic=False, count=0):
+    """ZK_MSM_FLAG_PRECOMPUTED: one bucket set over the table of window multiples [2^(c w)] P_i (zk_bases_precompute) --
+    against the default form and the oracle; single MSMs and a batch"""
+    sf = pyref.CURVES[cname][1]
+    pts = bases_for(cname, n)
+    sc = scalars_for(cname, n, seed, realistic)
+    exp = orc.msm_ark(cname, pts, sc, threads=8)
+    bases = zk.Bases(cname, pts)
+    bases.precompute(window_bits)
+    got = affine_of(zk, cname, zk.msm(bases, to_device(zk, sc), window_bits=window_bits, precomputed=True))
+    assert (got == exp).all(), (cname, n, window_bits)
+    got = affine_of(zk, cname, zk.msm(bases, to_device(zk, orc.to_mont(sf, sc)), montgomery=True, window_bits=window_bits, precomputed=True))
+    assert (got == exp).all(), (cname, n, window_bits, "montgomery")
+    if count:
+        cols = np.stack([scalars_for(cname, n, seed + 1 + i, realistic=(i % 2 == 1)) for i in range(count)])
+        got = zk.msm_batch(bases, to_device(zk, cols), window_bits=window_bits, precomputed=True)
+        for i in range(count):
+            assert (affine_of(zk, cname, got[i]) == orc.msm_ark(cname, pts, cols[i], threads=8)).all(), (cname, n, i, "batch")
+    bases.free()
+
+
 def check_msm_axis_reduce(zk, cname, n, window_bits_list, windows=None, seed=29):
     """the default bucket reduction (row / column sums, suffix scan + tree) over the shapes of its matrix: one row
     (c = 2, 3), rows = columns (odd c), rows = columns / 2 (even c), more columns than one workgroup holds (c = 16 on the

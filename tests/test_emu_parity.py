@@ -108,6 +108,12 @@ def test_msm_slice_lengths(zk):
     ps.check_msm_slice_lengths(zk, "Bn254G2", 60, 6)
 
 
+def test_msm_precomputed_table(zk):
+    ps.check_msm_precomputed(zk, "Vesta", 512, 8, count=3)
+    ps.check_msm_precomputed(zk, "Bls381G1", 256, 6, realistic=True)
+    ps.check_msm_precomputed(zk, "Bn254G2", 256, 5)
+
+
 def test_msm_axis_reduce(zk):
     ps.check_msm_axis_reduce(zk, "Vesta", 700, [2, 3, 4, 5, 8, 11])
     ps.check_msm_axis_reduce(zk, "Bn254G2", 300, [3, 6, 9])

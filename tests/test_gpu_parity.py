@@ -151,6 +151,12 @@ def test_msm_slice_lengths(zk, cname):
     ps.check_msm_slice_lengths(zk, cname, 1 << 13, 12)
 
 
+@pytest.mark.parametrize("cname,n,wb,count", [("Vesta", 1 << 16, 16, 3), ("Pallas", 1 << 18, 0, 0), ("Bls381G1", 1 << 14, 12, 2),
+                                              ("Bn254G2", 1 << 13, 10, 0), ("Vesta", 1 << 20, 0, 5)])
+def test_msm_precomputed_table(zk, cname, n, wb, count):
+    ps.check_msm_precomputed(zk, cname, n, wb, realistic=(cname == "Bls381G1"), count=count)
+
+
 @pytest.mark.parametrize("cname,n,wbs", [("Vesta", 1 << 14, [2, 3, 4, 7, 10, 13, 15, 16]), ("Bls381G1", 1 << 13, [5, 12, 16]),
                                          ("Bn254G2", 1 << 12, [3, 9, 14, 16]), ("Bls381G2", 1 << 12, [8, 15, 16])])
 def test_msm_axis_reduce(zk, cname, n, wbs):
