@@ -182,8 +182,9 @@ int zk_msm_collect(uint64_t ticket, void *out_jacobian_host);
 /* `count` MSMs over the SAME bases: scalars_dev holds count vectors of n scalars, vector k at element offset
  * k * stride_elems (stride_elems >= n); out_jacobian_host receives count results.  halo2 0.2 create_proof commits all
  * advice / lookup / permutation columns against one `Params::g_lagrange`; Groth16's a_query and b_g1_query MSMs share
- * the assignment instead (different bases: use submit/collect for those).  The MSMs alternate between two library
- * streams forked from `hip_stream` and joined back into it. */
+ * the assignment instead (different bases: use submit/collect for those).  Up to four vectors are summed by ONE launch
+ * sequence (their windows are more windows of the same sort / accumulate / reduce kernels); the sequences alternate between
+ * two library streams forked from `hip_stream` and joined back into it. */
 int zk_msm_batch_device(zk_curve_t c, uint64_t bases_handle, const void *scalars_dev, uint64_t n, uint32_t count,
                         uint64_t stride_elems, int scalars_are_montgomery, const zk_msm_opts *opts,
                         void *out_jacobian_host, void *hip_stream);
