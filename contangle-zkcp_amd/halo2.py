@@ -361,8 +361,11 @@ class IpaProverVirtual:
                 tdist.all_gather(outs, t)
                 for r, o in enumerate(outs):
                     g[r * share:(r + 1) * share] = o.numpy().view(np.uint64).reshape(share, 2 * nl)
-            elif tdist.get_backend() == "nccl":                             # RCCL over xGMI, device to device, in place
-                tdist.all_gather_into_tensor(g.view(-1), mine.reshape(-1).clone())
+            elif tdist.get_backend() == "nccl":                             # RCCL over xGMI, device to device (the same
+                t = mine.reshape(-1).clone()                                # all_gather form as dist._gather_add)
+                outs = [torch.empty_like(t) for _ in range(world)]
+                tdist.all_gather(outs, t)
+                g.view(-1).copy_(torch.cat(outs))
                 torch.cuda.synchronize()                                    # g is adopted as a bases handle next (another stream)
             else:                                                           # gloo rehearsal on a GPU box: staged through the host
                 t = mine.cpu()
