@@ -1118,6 +1118,20 @@ API int zk_inner_product_device(zk_field_t f, const void* a, const void* b, uint
     FIELD_SWITCH(f, return inner_product_run<F>(dc, (const Fe<F>*)a, (const Fe<F>*)b, n, out_host, (hipStream_t)stream));
     return ZK_ERR_INVALID_ARG;
 }
+API int zk_poly_eval_device(zk_field_t f, const void* c, uint64_t n, const void* x, void* out_host, void* stream) {
+    return zk_poly_eval_batch_device(f, c, n, 1, n, x, out_host, stream);
+}
+API int zk_poly_eval_batch_device(zk_field_t f, const void* c, uint64_t n, uint32_t count, uint64_t stride_elems, const void* x, void* out_host,
+                                  void* stream) {
+    if (!out_host || !x || stride_elems < n || (n && count && (!c || !aligned16(c)))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(c);
+    FIELD_SWITCH(f, {
+        Fe<F> xx;
+        host_load(xx, x);
+        return poly_eval_run<F>(dc, (const Fe<F>*)c, n, count, stride_elems, xx, (int)f, out_host, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
 API int zk_vec_fold_device(zk_field_t f, void* a, uint64_t half, const void* c, void* stream) {
     if (!c || (half && (!a || !aligned16(a)))) return ZK_ERR_INVALID_ARG;
     DEVICE_ENTRY(a);

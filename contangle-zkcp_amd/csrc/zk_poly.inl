@@ -168,6 +168,43 @@ int ipa_round_end_run(DeviceCtx& dc, hipStream_t st, void* vl_host, void* vr_hos
     return ZK_OK;
 }
 
+// p_q(x) for `count` resident coefficient vectors of n elements (stride apart), all at the same x (Montgomery form): one
+// launch, one copy.  Synchronises the stream (the results are host values).
+template <class F>
+int poly_eval_run(DeviceCtx& dc, const Fe<F>* c, uint64_t n, uint32_t count, uint64_t stride, const Fe<F>& x, int field, void* out_host,
+                  hipStream_t st) {
+    if (count == 0) return ZK_OK;
+    std::vector<Fe<F>> acc(count);
+    for (auto& a : acc) fe_zero(a);
+    if (n) {
+        if (n > (1ull << 30) || count > 65535) return ZK_ERR_UNSUPPORTED;
+        uint32_t logn = 0;
+        while ((1ull << logn) < n) logn++;
+        PowTables<F> pw;
+        ZK_TRY(pow_tables<F>(dc, x, logn < 1 ? 1 : logn, field, st, &pw));
+        StreamScratch* ss = nullptr;
+        ZK_TRY(stream_scratch(dc, st, &ss));
+        uint64_t blocks = ((n + EVAL_K - 1) / EVAL_K + 255) / 256;
+        if (blocks > 256) blocks = 256;
+        ZK_TRY(ws_get(ss->poly_tot, blocks * count * sizeof(Fe<F>)));
+#if defined(ZK_EMU)
+        for (uint32_t q = 0; q < count; q++)     // the test emulator launches one-dimensional grids
+            ZK_LAUNCH((poly_eval_kernel<F>), (unsigned)blocks, 256, 0, st, c + (uint64_t)q * stride, n, (uint64_t)0, x, pw,
+                      (Fe<F>*)ss->poly_tot.p + (uint64_t)q * blocks);
+#else
+        hipLaunchKernelGGL((poly_eval_kernel<F>), dim3((unsigned)blocks, count), dim3(256), 0, st, c, n, stride, x, pw, (Fe<F>*)ss->poly_tot.p);
+#endif
+        HIP_TRY(hipGetLastError());
+        std::vector<Fe<F>> part(blocks * count);
+        HIP_TRY(hipMemcpyAsync(part.data(), ss->poly_tot.p, blocks * count * sizeof(Fe<F>), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint32_t q = 0; q < count; q++)
+            for (uint64_t b = 0; b < blocks; b++) fe_add(acc[q], acc[q], part[(uint64_t)q * blocks + b]);
+    }
+    for (uint32_t q = 0; q < count; q++) host_store((unsigned char*)out_host + (size_t)q * sizeof(Fe<F>), acc[q]);
+    return ZK_OK;
+}
+
 template <class F>
 int vec_fold_run(Fe<F>* a, uint64_t half, const Fe<F>& c, hipStream_t st) {
     if (half == 0) return ZK_OK;

@@ -6,6 +6,7 @@
 //   lookup_factors_kernel          (A + beta)(S + gamma) and (A' + beta)(S' + gamma)
 //   inner_product_kernel           compute_inner_product (the value_l / value_r of an IPA round)
 //   vec_fold_kernel                a[i] += c a[i + half]  (the p' and b folds of an IPA round)
+//   poly_eval_kernel               eval_polynomial: p(x) for a resident coefficient vector
 //   expr_eval_kernel               the quotient numerator: a stack program over extended-domain columns with rotations
 // All HBM-streaming with a handful of Montgomery products per element; the scans are three launches (block products,
 // scan of the block totals by one workgroup, apply).
@@ -220,6 +221,44 @@ __global__ void __launch_bounds__(256) inner_product_kernel(const Fe<F>* __restr
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 // a[i] += c * a[i + half], i < half
+// p(x) = sum_i c_i x^i (halo2 arithmetic.rs eval_polynomial: the evaluations at x, omega x, ... that create_proof writes to the
+// transcript).  Lane t owns coefficients [t K, (t + 1) K): Horner inside the chunk, one multiplication by x^(t K) from the
+// power tables of x, then the block's tree sum; the host adds the per-block partial sums.  grid.y polynomials (stride apart) share x.
+constexpr uint32_t EVAL_K = 16;
+template <class F>
+__global__ void __launch_bounds__(256) poly_eval_kernel(const Fe<F>* __restrict__ c, uint64_t n, uint64_t stride, Fe<F> x, PowTables<F> pw,
+                                                        Fe<F>* __restrict__ partial) {
+    __shared__ Fe<F> part[256];
+    c += (uint64_t)blockIdx.y * stride;          // grid.y = polynomial (all evaluated at the same x)
+    partial += (uint64_t)blockIdx.y * gridDim.x;
+    Fe<F> acc;
+    fe_zero(acc);
+    const uint64_t lanes = (n + EVAL_K - 1) / EVAL_K;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < lanes; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t lo = t * EVAL_K;
+        const uint32_t cnt = n - lo < EVAL_K ? (uint32_t)(n - lo) : EVAL_K;
+        Fe<F> h = c[lo + cnt - 1];
+        for (int k = (int)cnt - 2; k >= 0; k--) {
+            fe_mul(h, h, x);
+            const Fe<F> ck = c[lo + k];
+            fe_add(h, h, ck);
+        }
+        mul_pow(h, pw, lo);
+        fe_add(acc, acc, h);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+            const Fe<F> o = part[threadIdx.x + d];
+            fe_add(acc, acc, o);
+            part[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) vec_fold_kernel(Fe<F>* __restrict__ a, uint64_t half, Fe<F> c) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (uint64_t)gridDim.x * blockDim.x) {

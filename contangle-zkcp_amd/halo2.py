@@ -19,7 +19,8 @@ from . import (Bases, _check, _np64, _ptr, base_limbs, curve_id, field_id, field
 
 PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo2_permutation_product_device",
                   "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
-                  "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device", "zk_ipa_collapse_range_device", "zk_ipa_round_device"]
+                  "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device", "zk_ipa_collapse_range_device", "zk_ipa_round_device",
+                  "zk_poly_eval_device", "zk_poly_eval_batch_device"]
 
 
 def best_multiexp(coeffs, bases):
@@ -155,6 +156,8 @@ def _plib():
     lib.zk_ipa_collapse_device.argtypes = [i32, u64, vp, u64, u64, vp, vp]
     lib.zk_ipa_collapse_range_device.argtypes = [i32, u64, vp, u64, u64, u64, u64, vp, vp]
     lib.zk_ipa_round_device.argtypes = [i32, u64, vp, vp, vp, u64, u64, vp, vp, vp, vp]
+    lib.zk_poly_eval_device.argtypes = [i32, vp, u64, vp, vp, vp]
+    lib.zk_poly_eval_batch_device.argtypes = [i32, vp, u64, ctypes.c_uint32, u64, vp, vp, vp]
     lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     return lib
 
@@ -204,6 +207,25 @@ def inner_product(field, a, b, stream=0):
     out = np.zeros(4, dtype=np.uint64)
     _check(_plib().zk_inner_product_device(field_id(field), _ptr(a), _ptr(b), int(a.shape[0]), _ptr(out), ctypes.c_void_p(stream)),
            "zk_inner_product_device")
+    return out
+
+
+def eval_polynomial(field, d_poly, x, stream=0):
+    """arithmetic.rs eval_polynomial: p(x) for a device-resident coefficient vector; x, result: Montgomery limbs"""
+    xx = _np64(x)
+    out = np.zeros(4, dtype=np.uint64)
+    _check(_plib().zk_poly_eval_device(field_id(field), _ptr(d_poly), int(d_poly.shape[0]), _ptr(xx), _ptr(out), ctypes.c_void_p(stream)),
+           "zk_poly_eval_device")
+    return out
+
+
+def eval_polynomials(field, d_polys, x, stream=0):
+    """d_polys: device buffer [count, n, 4]; every polynomial at the same x in one launch -> [count, 4]"""
+    xx = _np64(x)
+    count, n = int(d_polys.shape[0]), int(d_polys.shape[1])
+    out = np.zeros((count, 4), dtype=np.uint64)
+    _check(_plib().zk_poly_eval_batch_device(field_id(field), _ptr(d_polys), n, count, n, _ptr(xx), _ptr(out), ctypes.c_void_p(stream)),
+           "zk_poly_eval_batch_device")
     return out
 
 

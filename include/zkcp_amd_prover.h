@@ -128,6 +128,12 @@ int zk_halo2_lookup_product_device(zk_field_t f, const void *a_dev, const void *
  * p'[i] += u^-1 p'[i + half], b[i] += u b[i + half] as a[i] += c a[i + half] */
 int zk_inner_product_device(zk_field_t f, const void *a_dev, const void *b_dev, uint64_t n, void *out_mont_host, void *hip_stream);
 int zk_vec_fold_device(zk_field_t f, void *a_dev, uint64_t half, const void *c_mont_host, void *hip_stream);
+/* arithmetic.rs eval_polynomial: p(x) = sum_i coeffs[i] x^i for a resident coefficient vector (the evaluations create_proof
+ * writes to the transcript: every committed polynomial at x and at its rotations omega^r x).  x, the result: Montgomery, host. */
+int zk_poly_eval_device(zk_field_t f, const void *coeffs_dev, uint64_t n, const void *x_mont_host, void *out_mont_host, void *hip_stream);
+/* ... `count` polynomials of n coefficients (polynomial q at element offset q * stride_elems) at the same x: one launch, one copy */
+int zk_poly_eval_batch_device(zk_field_t f, const void *coeffs_dev, uint64_t n, uint32_t count, uint64_t stride_elems, const void *x_mont_host,
+                              void *out_mont_host, void *hip_stream);
 /* ... and the generator side (parallel_generator_collapse): g[i] <- affine(g[i] + [u] g[i + half]), i < half; g holds
  * 2 * half affine points (x, y) Montgomery on the device, u an element of the curve's scalar field (Montgomery, host) */
 int zk_ipa_fold_bases_device(zk_curve_t c, void *g_affine_dev, uint64_t half, const void *u_mont_host, void *hip_stream);

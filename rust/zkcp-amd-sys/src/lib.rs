@@ -231,6 +231,10 @@ extern "C" {
                                           z_last_out_host: *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_inner_product_device(f: c_int, a_dev: *const c_void, b_dev: *const c_void, n: u64, out_mont_host: *mut c_void,
                                    hip_stream: *mut c_void) -> c_int;
+    pub fn zk_poly_eval_device(f: c_int, coeffs_dev: *const c_void, n: u64, x_mont_host: *const c_void, out_mont_host: *mut c_void,
+                               hip_stream: *mut c_void) -> c_int;
+    pub fn zk_poly_eval_batch_device(f: c_int, coeffs_dev: *const c_void, n: u64, count: u32, stride_elems: u64, x_mont_host: *const c_void,
+                                     out_mont_host: *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_vec_fold_device(f: c_int, a_dev: *mut c_void, half: u64, c_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_ipa_fold_bases_device(c: c_int, g_affine_dev: *mut c_void, half: u64, u_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_ipa_virtual_scalars_device(f: c_int, p_dev: *const c_void, w_dev: *const c_void, m0: u64, cur: u64, sl_dev: *mut c_void,

@@ -701,6 +701,31 @@ def check_permutation_and_lookup_products(zk, name, k, ncols=5, seed=9):
     assert last == 1
 
 
+def check_eval_polynomial(zk, name, sizes=(1, 2, 15, 16, 17, 1000, 4099), seed=77):
+    """halo2 arithmetic.rs eval_polynomial on the device against Python integers (Horner); edge points 0, 1, p - 1"""
+    p = pyref.FIELDS[name][0]
+    rng = pyref.Rng(seed)
+    for n in sizes:
+        coeffs = [rng.below(p) for _ in range(n)]
+        d = to_device(zk, _monts(name, coeffs))
+        for x in (0, 1, p - 1, rng.below(p), rng.below(p)):
+            exp = 0
+            for c in reversed(coeffs):
+                exp = (exp * x + c) % p
+            got = zk.halo2.eval_polynomial(name, d, _monts(name, [x])[0])
+            assert (got == _monts(name, [exp])[0]).all(), (name, n, x)
+    # several polynomials at one point in one launch
+    n, count = 300, 5
+    polys = [[rng.below(p) for _ in range(n)] for _ in range(count)]
+    x = rng.below(p)
+    got = zk.halo2.eval_polynomials(name, to_device(zk, np.stack([_monts(name, c) for c in polys])), _monts(name, [x])[0])
+    for q in range(count):
+        exp = 0
+        for c in reversed(polys[q]):
+            exp = (exp * x + c) % p
+        assert (got[q] == _monts(name, [exp])[0]).all(), (name, "batch", q)
+
+
 def check_ipa(zk, cname, k, seed=13):
     """halo2_proofs 0.2 inner-product argument rounds on the device (two MSMs, two inner products, three folds per round)
     against the pure-Python restatement; the folded generator equals <s, G> with s_i = prod_j u_j^(bit_j(i))"""

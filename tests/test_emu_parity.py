@@ -174,6 +174,11 @@ def test_halo2_products(zk):
     ps.check_permutation_and_lookup_products(zk, "PallasFp", 6)
 
 
+def test_halo2_eval_polynomial(zk):
+    ps.check_eval_polynomial(zk, "PallasFp")
+    ps.check_eval_polynomial(zk, "Bls381Fr", sizes=(3, 300))
+
+
 def test_halo2_ipa(zk):
     ps.check_ipa(zk, "Vesta", 4)
     ps.check_ipa(zk, "Pallas", 2)

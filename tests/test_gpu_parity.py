@@ -498,6 +498,11 @@ def test_halo2_permutation_and_lookup_products(zk, name, k):
     ps.check_permutation_and_lookup_products(zk, name, k)
 
 
+@pytest.mark.parametrize("name", ["PallasFp", "PallasFq", "Bn254Fr"])
+def test_halo2_eval_polynomial(zk, name):
+    ps.check_eval_polynomial(zk, name, sizes=(1, 17, 4099, (1 << 16) + 3))
+
+
 @pytest.mark.parametrize("cname,k", [("Vesta", 6), ("Pallas", 5), ("Bn254G1", 4), ("Bls381G1", 3)])   # the argument is halo2's (Pasta); the entry points take every curve
 def test_halo2_ipa(zk, cname, k):
     ps.check_ipa(zk, cname, k)
