@@ -1118,6 +1118,16 @@ API int zk_inner_product_device(zk_field_t f, const void* a, const void* b, uint
     FIELD_SWITCH(f, return inner_product_run<F>(dc, (const Fe<F>*)a, (const Fe<F>*)b, n, out_host, (hipStream_t)stream));
     return ZK_ERR_INVALID_ARG;
 }
+API int zk_vec_muladd_device(zk_field_t f, void* a, const void* b, uint64_t n, const void* s, void* stream) {
+    if (!s || (n && (!a || !b || !aligned16(a) || !aligned16(b)))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(a);
+    FIELD_SWITCH(f, {
+        Fe<F> ss;
+        host_load(ss, s);
+        return vec_muladd_run<F>((Fe<F>*)a, (const Fe<F>*)b, n, ss, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
 API int zk_poly_eval_device(zk_field_t f, const void* c, uint64_t n, const void* x, void* out_host, void* stream) {
     return zk_poly_eval_batch_device(f, c, n, 1, n, x, out_host, stream);
 }

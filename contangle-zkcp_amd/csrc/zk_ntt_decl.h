@@ -36,6 +36,8 @@ int lookup_product_run(DeviceCtx& dc, const Fe<F>* A, const Fe<F>* S, const Fe<F
 template <class F>
 int inner_product_run(DeviceCtx& dc, const Fe<F>* a, const Fe<F>* b, uint64_t n, void* out_host, hipStream_t st);
 template <class F>
+int vec_muladd_run(Fe<F>* a, const Fe<F>* b, uint64_t n, const Fe<F>& s, hipStream_t st);
+template <class F>
 int poly_eval_run(DeviceCtx& dc, const Fe<F>* c, uint64_t n, uint32_t count, uint64_t stride, const Fe<F>& x, int field, void* out_host, hipStream_t st);
 template <class F>
 int vec_fold_run(Fe<F>* a, uint64_t half, const Fe<F>& c, hipStream_t st);

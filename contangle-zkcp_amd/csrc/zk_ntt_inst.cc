@@ -12,6 +12,7 @@ template int perm_product_run<ZK_FIELD>(DeviceCtx&, int, uint32_t, const void* c
 template int lookup_product_run<ZK_FIELD>(DeviceCtx&, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>&,
                                           const Fe<ZK_FIELD>&, uint64_t, const Fe<ZK_FIELD>&, Fe<ZK_FIELD>*, void*, hipStream_t);
 template int inner_product_run<ZK_FIELD>(DeviceCtx&, const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, uint64_t, void*, hipStream_t);
+template int vec_muladd_run<ZK_FIELD>(Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, uint64_t, const Fe<ZK_FIELD>&, hipStream_t);
 template int poly_eval_run<ZK_FIELD>(DeviceCtx&, const Fe<ZK_FIELD>*, uint64_t, uint32_t, uint64_t, const Fe<ZK_FIELD>&, int, void*, hipStream_t);
 template int vec_fold_run<ZK_FIELD>(Fe<ZK_FIELD>*, uint64_t, const Fe<ZK_FIELD>&, hipStream_t);
 template int ipa_virtual_scalars_run<ZK_FIELD>(const Fe<ZK_FIELD>*, const Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, uint64_t, uint64_t, hipStream_t);

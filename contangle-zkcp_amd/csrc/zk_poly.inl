@@ -206,6 +206,16 @@ int poly_eval_run(DeviceCtx& dc, const Fe<F>* c, uint64_t n, uint32_t count, uin
 }
 
 template <class F>
+int vec_muladd_run(Fe<F>* a, const Fe<F>* b, uint64_t n, const Fe<F>& s, hipStream_t st) {
+    if (n == 0) return ZK_OK;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    ZK_LAUNCH((vec_muladd_kernel<F>), (unsigned)blocks, 256, 0, st, a, b, n, s);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+template <class F>
 int vec_fold_run(Fe<F>* a, uint64_t half, const Fe<F>& c, hipStream_t st) {
     if (half == 0) return ZK_OK;
     uint64_t blocks = (half + 255) / 256;

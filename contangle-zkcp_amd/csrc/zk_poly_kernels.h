@@ -221,6 +221,19 @@ __global__ void __launch_bounds__(256) inner_product_kernel(const Fe<F>* __restr
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 // a[i] += c * a[i + half], i < half
+// a[i] = a[i] * s + b[i]: one Horner step of the multiopen combination (poly/multiopen/prover.rs: the polynomials queried at the
+// same point set are folded with powers of x_1, the per-set quotients with x_4) on resident coefficient vectors
+template <class F>
+__global__ void __launch_bounds__(256) vec_muladd_kernel(Fe<F>* __restrict__ a, const Fe<F>* __restrict__ b, uint64_t n, Fe<F> s) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<F> x = a[i];
+        const Fe<F> y = b[i];
+        fe_mul(x, x, s);
+        fe_add(x, x, y);
+        a[i] = x;
+    }
+}
+
 // p(x) = sum_i c_i x^i (halo2 arithmetic.rs eval_polynomial: the evaluations at x, omega x, ... that create_proof writes to the
 // transcript).  Lane t owns coefficients [t K, (t + 1) K): Horner inside the chunk, one multiplication by x^(t K) from the
 // power tables of x, then the block's tree sum; the host adds the per-block partial sums.  grid.y polynomials (stride apart) share x.

@@ -20,7 +20,7 @@ from . import (Bases, _check, _np64, _ptr, base_limbs, curve_id, field_id, field
 PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo2_permutation_product_device",
                   "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
                   "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device", "zk_ipa_collapse_range_device", "zk_ipa_round_device",
-                  "zk_poly_eval_device", "zk_poly_eval_batch_device"]
+                  "zk_poly_eval_device", "zk_poly_eval_batch_device", "zk_vec_muladd_device"]
 
 
 def best_multiexp(coeffs, bases):
@@ -157,6 +157,7 @@ def _plib():
     lib.zk_ipa_collapse_range_device.argtypes = [i32, u64, vp, u64, u64, u64, u64, vp, vp]
     lib.zk_ipa_round_device.argtypes = [i32, u64, vp, vp, vp, u64, u64, vp, vp, vp, vp]
     lib.zk_poly_eval_device.argtypes = [i32, vp, u64, vp, vp, vp]
+    lib.zk_vec_muladd_device.argtypes = [i32, vp, vp, u64, vp, vp]
     lib.zk_poly_eval_batch_device.argtypes = [i32, vp, u64, ctypes.c_uint32, u64, vp, vp, vp]
     lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     return lib
@@ -208,6 +209,13 @@ def inner_product(field, a, b, stream=0):
     _check(_plib().zk_inner_product_device(field_id(field), _ptr(a), _ptr(b), int(a.shape[0]), _ptr(out), ctypes.c_void_p(stream)),
            "zk_inner_product_device")
     return out
+
+
+def vec_muladd(field, a, b, s, stream=0):
+    """a[i] = a[i] * s + b[i] (multiopen: folding the polynomials of a point set with powers of x_1)"""
+    ss = _np64(s)
+    _check(_plib().zk_vec_muladd_device(field_id(field), _ptr(a), _ptr(b), int(a.shape[0]), _ptr(ss), ctypes.c_void_p(stream)), "zk_vec_muladd_device")
+    return a
 
 
 def eval_polynomial(field, d_poly, x, stream=0):

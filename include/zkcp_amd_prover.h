@@ -128,6 +128,9 @@ int zk_halo2_lookup_product_device(zk_field_t f, const void *a_dev, const void *
  * p'[i] += u^-1 p'[i + half], b[i] += u b[i + half] as a[i] += c a[i + half] */
 int zk_inner_product_device(zk_field_t f, const void *a_dev, const void *b_dev, uint64_t n, void *out_mont_host, void *hip_stream);
 int zk_vec_fold_device(zk_field_t f, void *a_dev, uint64_t half, const void *c_mont_host, void *hip_stream);
+/* poly/multiopen/prover.rs: a[i] = a[i] * s + b[i] -- one Horner step of folding the polynomials queried at the same point set with
+ * powers of x_1 (and the per-set quotients with x_4), on resident coefficient vectors.  s: Montgomery, host. */
+int zk_vec_muladd_device(zk_field_t f, void *a_dev, const void *b_dev, uint64_t n, const void *s_mont_host, void *hip_stream);
 /* arithmetic.rs eval_polynomial: p(x) = sum_i coeffs[i] x^i for a resident coefficient vector (the evaluations create_proof
  * writes to the transcript: every committed polynomial at x and at its rotations omega^r x).  x, the result: Montgomery, host. */
 int zk_poly_eval_device(zk_field_t f, const void *coeffs_dev, uint64_t n, const void *x_mont_host, void *out_mont_host, void *hip_stream);

@@ -233,6 +233,7 @@ extern "C" {
                                    hip_stream: *mut c_void) -> c_int;
     pub fn zk_poly_eval_device(f: c_int, coeffs_dev: *const c_void, n: u64, x_mont_host: *const c_void, out_mont_host: *mut c_void,
                                hip_stream: *mut c_void) -> c_int;
+    pub fn zk_vec_muladd_device(f: c_int, a_dev: *mut c_void, b_dev: *const c_void, n: u64, s_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_poly_eval_batch_device(f: c_int, coeffs_dev: *const c_void, n: u64, count: u32, stride_elems: u64, x_mont_host: *const c_void,
                                      out_mont_host: *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_vec_fold_device(f: c_int, a_dev: *mut c_void, half: u64, c_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;

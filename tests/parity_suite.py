@@ -714,6 +714,11 @@ def check_eval_polynomial(zk, name, sizes=(1, 2, 15, 16, 17, 1000, 4099), seed=7
                 exp = (exp * x + c) % p
             got = zk.halo2.eval_polynomial(name, d, _monts(name, [x])[0])
             assert (got == _monts(name, [exp])[0]).all(), (name, n, x)
+    # the multiopen Horner step a = a s + b
+    n = 1000
+    a, b, sc = [rng.below(p) for _ in range(n)], [rng.below(p) for _ in range(n)], rng.below(p)
+    got = to_host(zk, zk.halo2.vec_muladd(name, to_device(zk, _monts(name, a)), to_device(zk, _monts(name, b)), _monts(name, [sc])[0]))
+    assert (got == _monts(name, [(x_ * sc + y_) % p for x_, y_ in zip(a, b)])).all(), (name, "muladd")
     # several polynomials at one point in one launch
     n, count = 300, 5
     polys = [[rng.below(p) for _ in range(n)] for _ in range(count)]
