@@ -180,10 +180,34 @@ int poly_eval_run(DeviceCtx& dc, const Fe<F>* c, uint64_t n, uint32_t count, uin
         if (n > (1ull << 30) || count > 65535) return ZK_ERR_UNSUPPORTED;
         uint32_t logn = 0;
         while ((1ull << logn) < n) logn++;
-        PowTables<F> pw;
-        ZK_TRY(pow_tables<F>(dc, x, logn < 1 ? 1 : logn, field, st, &pw));
         StreamScratch* ss = nullptr;
         ZK_TRY(stream_scratch(dc, st, &ss));
+        // the power tables of x (g^j for j < 1024 and g^(1024 j)) are built in the stream's scratch for this call: an evaluation
+        // point is a fresh transcript challenge, caching it beside the NTT twiddle tables would only evict those
+        (void)field;
+        if (logn < 1) logn = 1;
+        const uint64_t nlo = logn >= 10 ? 1024 : (1ull << logn), nhi = logn > 10 ? (1ull << (logn - 10)) : 1;
+        ZK_TRY(ws_get(ss->poly_b, sizeof(Fe<F>) * (nlo + nhi + 64)));
+        Fe<F>* tbl = (Fe<F>*)ss->poly_b.p;
+        Fe<F>* d_lad = tbl + nlo + nhi;
+        std::vector<Fe<F>> lad(64);
+        {
+            Fe<F> w = x;
+            for (int k = 0; k < 10; k++) {
+                lad[k] = w;
+                fe_sqr(w, w);
+            }
+            for (int k = 0; k < 22; k++) {   // w = x^1024 here
+                lad[32 + k] = w;
+                fe_sqr(w, w);
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(d_lad, lad.data(), sizeof(Fe<F>) * 64, hipMemcpyHostToDevice, st));
+        ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nlo + 255) / 256), 256, 0, st, tbl, (const Fe<F>*)d_lad, nlo, 10);
+        ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nhi + 255) / 256), 256, 0, st, tbl + nlo, (const Fe<F>*)(d_lad + 32), nhi, 22);
+        PowTables<F> pw;
+        pw.lo = tbl;
+        pw.hi = tbl + nlo;
         uint64_t blocks = ((n + EVAL_K - 1) / EVAL_K + 255) / 256;
         if (blocks > 256) blocks = 256;
         ZK_TRY(ws_get(ss->poly_tot, blocks * count * sizeof(Fe<F>)));
