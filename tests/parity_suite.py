@@ -116,7 +116,7 @@ def check_msm_golden(zk):
             n = case["n"]
             pts, sc, exp = golden_msm_case(cname, case)
             bases = zk.Bases(cname, pts)
-            for wb in (0, 3, 7):
+            for wb in ((0, 3, 7) if not zk.backend_info().startswith("emu") else (0, 6)):   # the CPU emulator pays per launched lane
                 got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=wb))
                 assert (got == exp).all(), (cname, n, wb)
             got = affine_of(zk, cname, zk.ark.VariableBaseMSM.multi_scalar_mul(bases, sc))
@@ -473,7 +473,7 @@ def check_multi_device(zk, ndev):
     the partial sums are added on the host; host-pointer and device-pointer entries, more devices than windows, an
     explicit window range (stays on the home device), batches and deferred results on a multi-device process"""
     assert zk.device_count() == ndev
-    for cname, n, wb in (("Vesta", 700, 0), ("Bls381G1", 300, 7), ("Bn254G2", 90, 5), ("Pallas", 50, 16)):
+    for cname, n, wb in (("Vesta", 700, 0), ("Bls381G1", 300, 7), ("Bn254G2", 90, 5), ("Pallas", 50, 13)):
         pts = bases_for(cname, n)
         sc = scalars_for(cname, n, 71, realistic=True)
         exp = orc.msm_ark(cname, pts, sc, threads=8)
