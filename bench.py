@@ -7,14 +7,15 @@ the configuration `metric` is quoted on), inputs resident in HBM, through the C 
       circuits-halo2/src/encryption.rs:83-161; SURVEY 8a a11 / 8d "Config 3"), in upstream's order -- see bench_halo2():
       advice commits + NTT chains, lookup and permutation grand products with their commits and chains, the quotient
       (expression evaluation on the extended coset, division by the vanishing polynomial, extended_to_coeff, 8 h-piece
-      commits) and the k-round inner-product argument.  NTT chains run on a second HIP stream beside the batched MSMs.
-      RNG, transcript and the lookup's sort stay on the CPU; evaluations at x / the multiopen combination are not in the list.
+      commits), the evaluations at x and its rotations with their multiopen folds, and the k-round inner-product argument.  NTT
+      chains run on a second HIP stream beside the batched MSMs.  RNG, transcript and the lookup's sort stay on the CPU.
   metric    = constraints/sec = rows / wall-clock of the timed region (whole job)
   --workload column : BASELINE configs[1], one 2^20 MSM + one 2^20 NTT per step (the microbench; prints msm_mops)
   --workload groth16: the GPU work of one Groth16 proof at domain 2^logn (SURVEY 8d "Config 4")
-  N > 1     = every MSM is window-range sharded over the N ranks (one process per GPU) and combined with one all_gather
-              of Jacobian points over RCCL (contangle-zkcp_amd/dist.py); NTTs stay single-GPU, columns are dealt
-              round-robin.  Total work per step is fixed -> "scaling": "strong".
+  N > 1     = every MSM of 2^17 points or more is window-range sharded over the N ranks (one process per GPU) and combined with
+              one all_gather of Jacobian points over RCCL (contangle-zkcp_amd/dist.py), the IPA's generator collapse by output
+              range; NTT chains, the quotient expression and the small IPA rounds run on every rank.  Total work per step is
+              fixed -> "scaling": "strong".
 
 Launch: `python bench.py [--gpus 1 --steps K --warmup W]`, or for N > 1
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`.
