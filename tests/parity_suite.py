@@ -795,6 +795,49 @@ def check_ipa(zk, cname, k, seed=13):
     srs.free()
 
 
+def check_ipa_collapse_edges(zk, cname, k=6, seed=19):
+    """zk_ipa_collapse_device at its edges: no round done yet (T = 1: a copy of the generators), every round done (one
+    survivor, T = 2^k scalars), and zk_ipa_collapse_range_device shares that tile the output -- all against the literal folds"""
+    import ctypes
+    from oracle import pyref_halo2 as h2
+    sf = pyref.CURVES[cname][1]
+    r = pyref.FIELDS[sf][0]
+    n = 1 << k
+    rng = pyref.Rng(seed)
+    gens = bases_for(cname, n, seed=33)
+    L = orc.coord_limbs(cname)
+    us = [1 + rng.below(r - 1) for _ in range(k)]
+    # literal folds on the device (IpaProver) give the reference generators after every round
+    ipa = zk.halo2.IpaProver(cname, to_device(zk, rand_field(sf, n, 1)), to_device(zk, rand_field(sf, n, 2)), to_device(zk, gens.copy()))
+    g_after = {0: gens.copy()}
+    for j in range(k):
+        ipa.fold(_monts(sf, [us[j]])[0])
+        g_after[j + 1] = to_host(zk, ipa.g)[:n >> (j + 1)].copy()
+    ipa.free()
+    srs = zk.Bases(cname, gens)
+    new_buffer = lambda shape: to_device(zk, np.zeros(shape, dtype=np.uint64))
+    plib = zk.halo2._plib()
+    for rounds in (0, 2, k):
+        v = zk.halo2.IpaProverVirtual(cname, to_device(zk, rand_field(sf, n, 1)), to_device(zk, rand_field(sf, n, 2)), srs, new_buffer)
+        for j in range(rounds):
+            v.fold(_monts(sf, [us[j]])[0])
+        cur = n >> rounds
+        # shares [0, a), [a, cur) through the range entry, then the whole thing
+        a = max(1, cur // 3)
+        parts = []
+        for first, count in ((0, a), (a, cur - a)):
+            if count == 0:
+                continue
+            out = new_buffer((count, 2 * L))
+            st = plib.zk_ipa_collapse_range_device(zk.curve_id(cname), srs.handle, zk._ptr(v.W), n, cur, first, count, zk._ptr(out), ctypes.c_void_p(0))
+            assert st == 0, (cname, rounds, first, count, st)
+            parts.append(to_host(zk, out).reshape(count, 2 * L))
+        assert (np.concatenate(parts) == g_after[rounds]).all(), (cname, rounds, "ranges")
+        assert (to_host(zk, v.collapse()) == g_after[rounds]).all(), (cname, rounds, "whole")
+        v.free()
+    srs.free()
+
+
 def check_expression(zk, name, k, ext=2, seed=21):
     """the quotient-numerator evaluator: a small gate set in the style of the reference's circuit (a multiplication gate
     behind a selector, a Pow5-style S-box with a rotation, a boolean check), folded with y, over extended-domain columns"""

@@ -174,6 +174,10 @@ def test_halo2_products(zk):
     ps.check_permutation_and_lookup_products(zk, "PallasFp", 6)
 
 
+def test_halo2_ipa_collapse_edges(zk):
+    ps.check_ipa_collapse_edges(zk, "Vesta", 5)
+
+
 def test_halo2_eval_polynomial(zk):
     ps.check_eval_polynomial(zk, "PallasFp")
     ps.check_eval_polynomial(zk, "Bls381Fr", sizes=(3, 300))

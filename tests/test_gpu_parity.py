@@ -498,6 +498,11 @@ def test_halo2_permutation_and_lookup_products(zk, name, k):
     ps.check_permutation_and_lookup_products(zk, name, k)
 
 
+@pytest.mark.parametrize("cname,k", [("Vesta", 8), ("Pallas", 12)])
+def test_halo2_ipa_collapse_edges(zk, cname, k):
+    ps.check_ipa_collapse_edges(zk, cname, k)
+
+
 @pytest.mark.parametrize("name", ["PallasFp", "PallasFq", "Bn254Fr"])
 def test_halo2_eval_polynomial(zk, name):
     ps.check_eval_polynomial(zk, name, sizes=(1, 17, 4099, (1 << 16) + 3))
