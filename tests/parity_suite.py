@@ -458,6 +458,20 @@ def check_msm_batch(zk, cname, n, count, window_bits=0):
     got = zk.msm_batch(bases, to_device(zk, mont), montgomery=True, window_bits=window_bits)
     for i in range(count):
         assert (affine_of(zk, cname, got[i]) == exp[i]).all(), (cname, n, i, "montgomery")
+    # vectors further apart than n (stride_elems > n), straight through the C entry
+    import ctypes
+    pad = 5
+    padded = np.zeros((count, n + pad, 4), dtype=np.uint64)
+    padded[:, :n] = cols
+    padded[:, n:] = 0xFFFFFFFFFFFFFFFF           # garbage between the vectors must not be read
+    d_pad = to_device(zk, padded)
+    nl = zk.base_limbs(cname)
+    out = np.zeros((count, 3 * nl), dtype=np.uint64)
+    st = zk.load().zk_msm_batch_device(zk.curve_id(cname), bases.handle, zk._ptr(d_pad), n, count, n + pad, 0,
+                                       ctypes.byref(zk.msm_opts(window_bits)), zk._ptr(out), ctypes.c_void_p(0))
+    assert st == 0
+    for i in range(count):
+        assert (affine_of(zk, cname, out[i]) == exp[i]).all(), (cname, n, i, "stride")
     # a window share of every vector (the sharded form): up to 4 vectors ride in one job, each keeps its own windows
     W = zk.msm_window_count(cname, n, window_bits)
     if W >= 2:
