@@ -244,112 +244,111 @@ def base_line(e, value, elapsed, workload, cfg):
 
 
 # ---------------------------------------------------------------------------------------------------- halo2 (default)
-N_FIXED, N_PERM_COLS, PERM_CHUNK, N_H_PIECES = 8, 16, 7, 8     # reference circuit: 8 fixed columns; equality over 16 columns; degree 9
-
-
-def quotient_program(n_adv, n_fix):
-    """A gate set in the style of the reference's circuit (circuits-halo2/src/encryption.rs:83-161: ECC-style multiplication
-    gates, a Pow5 S-box with a rotation, boolean / range checks behind fixed selectors, the lookup and permutation argument
-    constraints), folded with y: columns [0, n_adv) advice, [n_adv, n_adv + n_fix) fixed, then A', S', Z_lookup, Z_perm x3.
-    consts: [y, 5, 1, beta, gamma]"""
-    A = lambda i, r=0: ("col", i % n_adv, r)
-    Fx = lambda i, r=0: ("col", n_adv + i % n_fix, r)
-    X = n_adv + n_fix
-    ap, sp, zl = ("col", X, 0), ("col", X + 1, 0), ("col", X + 2, 0)
-    zp = [("col", X + 3 + c, 0) for c in range(3)]
-    prog = []
-    # every term after the first is folded in as  acc = acc * y + term
-    # multiplication gates  q (a b - c), eight of them
-    first = True
-    for g in range(8):
-        term = [Fx(g), A(g), A(g + 1), ("mul",), A(g + 2), ("sub",), ("mul",)]
-        prog.extend(term if first else [("scale", 0)] + term + [("add",)])
-        first = False
-    # Pow5 with a rotation  q (a^5 + 5 - b(omega X)), three of them
-    for g in range(3):
-        a = A(3 * g + 1)
-        prog.extend([("scale", 0), Fx(g + 3), a, a, ("mul",), a, ("mul",), a, ("mul",), a, ("mul",), ("const", 1), ("add",),
-                     ("col", (3 * g + 2) % n_adv, 1), ("sub",), ("mul",), ("add",)])
-    # boolean checks  q a (a - 1), four of them
-    for g in range(4):
-        a = A(g + 9)
-        prog.extend([("scale", 0), Fx(g + 4), a, a, ("const", 2), ("sub",), ("mul",), ("mul",), ("add",)])
-    # lookup: Z(omega X)(A' + beta)(S' + gamma) - Z(X)(A + beta)(S + gamma), and (A' - S')(A' - A'(omega^-1 X))
-    prog.extend([("scale", 0), ("col", X + 2, 1), ap, ("const", 3), ("add",), ("mul",), sp, ("const", 4), ("add",), ("mul",),
-                 zl, A(0), ("const", 3), ("add",), ("mul",), Fx(7), ("const", 4), ("add",), ("mul",), ("sub",), ("add",)])
-    prog.extend([("scale", 0), ap, sp, ("sub",), ap, ("col", X, -1), ("sub",), ("mul",), ("add",)])
-    # permutation, per chunk: Z(omega X) prod (v + beta s + gamma) - Z(X) prod (v + delta-term + gamma), two columns of each chunk written out
-    for c in range(3):
-        v0, v1 = A(2 * c), A(2 * c + 1)
-        prog.extend([("scale", 0), ("col", X + 3 + c, 1), v0, Fx(c), ("scale", 3), ("add",), ("const", 4), ("add",), ("mul",),
-                     v1, Fx(c + 1), ("scale", 3), ("add",), ("const", 4), ("add",), ("mul",),
-                     zp[c], v0, ("const", 4), ("add",), ("mul",), v1, ("const", 3), ("add",), ("mul",), ("sub",), ("add",)])
-    return prog
+# the reference circuit (circuits-halo2/src/encryption.rs:83-161, :143-148): 13 advice, 8 fixed, 3 instance columns, one lookup,
+# equality over 16 columns (13 advice + 3 instance) in chunks of 7, degree-9 gates -> 8 quotient pieces
+N_INST, N_FIXED, N_PERM_COLS, PERM_CHUNK, N_H_PIECES = 3, 8, 16, 7, 8
 
 
 def bench_halo2(e):
     """The device work-list of one halo2_proofs 0.2 create_proof over a 2^k-row circuit with the reference circuit's column
-    layout, in upstream's order; RNG (blinding rows / scalars), the transcript and the sort of the lookup's permuted columns
-    stay on the CPU and are represented by pre-made inputs / fixed challenges:
-      1 advice        13 x commit (batched MSM, Lagrange basis)   +  13 x (lagrange_to_coeff ; coeff_to_extended)
-      2 lookup        commit A', S' ; product Z_L (grand product) ; commit Z_L ; 3 x (l2c ; c2e)
-      3 permutation   3 chunks of <= 7 columns: product Z_P (each chunk continues the previous) ; 3 commits ; 3 x (l2c ; c2e)
-      4 quotient      commit the random polynomial ; gate / lookup / permutation expressions on the extended coset (one stack
-                      program, 268 ops of which 81 products, 27 columns) ; divide by the vanishing polynomial ; extended_to_coeff ; commit the 8 pieces of h
-      5 opening       60 evaluations of resident polynomials at x, omega x, omega^-1 x and their multiopen folds; the inner-product argument on the combined
-                      polynomial: k rounds of 2 MSMs + 2 inner products + 3 folds
-    """
+    layout, in upstream's order; RNG (blinding rows / scalars, the random polynomials), the transcript and the sort of the
+    lookup's permuted columns stay on the CPU and are represented by pre-made inputs / fixed challenges:
+      0 instance      3 x commit (Lagrange basis) + 3 x (lagrange_to_coeff ; coeff_to_extended)
+      1 advice        13 x commit (one batched MSM call with the instance columns) + 13 NTT chains
+      2 lookup        commit A', S' ; 2 chains               [permute_expression_pair: CPU]
+      3 permutation   3 chunks of <= 7 columns: product Z_P (each chunk continues the previous) ; 3 commits ; 3 chains
+      4 lookup        product Z_L ; commit ; chain
+      5 vanishing     commit the random polynomial
+      6 quotient      the gate / lookup / permutation expressions on the extended coset (one stack program, 268 ops of which 81
+                      products, 30 columns) ; divide by the vanishing polynomial ; extended_to_coeff ; commit the 8 pieces of h
+      7 evaluations   h(X) = sum x^(n i) h_i ; 58 evaluations of resident coefficient vectors at x, omega x, omega^-1 x, omega^last x
+      8 multiopen     4 point sets: fold each set's polynomials with x_1 (Horner) ; kate_division by every point of the set ; fold
+                      the sets with x_2 -> q' ; commit q' ; evaluate the 4 set polynomials at x_3 ; fold q' and the sets with x_4 -> p
+      9 opening       the inner-product argument on p: commit the blinding polynomial s ; p' = s xi + p ; p'(x_3) ; b = powers of
+                      x_3 ; k rounds of 2 MSMs + 2 inner products + 3 folds
+    A chain keeps BOTH forms of its column: the coefficients (out of place, for steps 7-8) and the extended coset.
+    N > 1 ranks (one process per GPU): every MSM of 2^17 points or more is window-range sharded; the extended coset is split
+    into N sub-cosets (rank j: the points ZETA w_ext^(iN + j)) so that the coset transforms, the expression and the division
+    by the vanishing polynomial are sharded with no exchange, then ONE all_gather of h (32 B per extended row)."""
     a, zk, torch, np = e.args, e.zk, e.torch, e.np
+    H = zk.halo2
     curve = a.curve if a.curve in ("Vesta", "Pallas") else "Vesta"
     sfield = e.synth.CURVE_SCALAR_FIELD[curve]
     k, ext = a.logn, a.logn + 3
     n, ne = 1 << k, 1 << (a.logn + 3)
     g_lagrange, d_pts = make_bases(e, curve, n, 0x5EED)
-    g_coeff, d_pts_c = make_bases(e, curve, n, 0x5EEE)          # Params::g (coefficient basis): h pieces, random poly, IPA
-    dom = zk.halo2.EvaluationDomain(sfield, 9, k)      # degree-9 gates -> extended_k = k + 3 (Orchard-style, SURVEY a10)
+    g_coeff, d_pts_c = make_bases(e, curve, n, 0x5EEE)          # Params::g (coefficient basis): h pieces, random polys, q', IPA
+    dom = H.EvaluationDomain(sfield, 9, k)             # degree-9 gates -> extended_k = k + 3 (Orchard-style, SURVEY a10)
     assert dom.extended_k == ext
-    rf = lambda seed, m=n: e.synth.rand_field(sfield, m, seed)
-    cols_host = np.stack([rf(0xC0DE + c) for c in range(NCOL)])
-    d_cols = to_dev(e, cols_host)                                   # [13, n, 4] advice, Lagrange form
-    d_fixed_ext = [to_dev(e, rf(0xF1 + c, ne)) for c in range(N_FIXED)]          # fixed columns on the extended coset: key material
-    d_sigma = [to_dev(e, rf(0x51 + c)) for c in range(N_PERM_COLS)]              # permutation polynomials (Lagrange): key material
+    parts = e.world if e.world in (1, 2, 4, 8) else 1       # sub-cosets of the extended domain, one per rank
+    part = e.rank if parts > 1 else 0
+    m, rsc = ne // parts, dom.rot_scale_part(parts)
+    rf = lambda seed, cnt=n: e.synth.rand_field(sfield, cnt, seed)
+    newbuf = lambda *shape: torch.empty(shape + (4,), dtype=torch.int64, device="cuda")
+    # ---- inputs: Lagrange columns (instance 0..2, advice 3..15: one buffer, one batched commitment), lookup columns, challenges
+    NLAG = N_INST + NCOL
+    lag_host = np.stack([rf(0x1D0 + c) for c in range(N_INST)] + [rf(0xC0DE + c) for c in range(NCOL)])
+    d_lag = to_dev(e, lag_host)
     d_lookup = to_dev(e, np.stack([rf(0xA0), rf(0xA1), rf(0xA2), rf(0xA3)]))     # A, S and the permuted A', S' (the sort is upstream's CPU step)
-    d_rand = to_dev(e, rf(0xBB))                                                  # the vanishing argument's random polynomial
+    d_sigma = [to_dev(e, rf(0x51 + c)) for c in range(N_PERM_COLS)]              # permutation polynomials (Lagrange): key material
+    d_fixed_cos = [to_dev(e, rf(0xF1 + c + 64 * part, m)) for c in range(N_FIXED)]   # fixed columns on this rank's sub-coset: key material
     beta, gamma, delta, y = (rf(0xC1, 1)[0], rf(0xC2, 1)[0], rf(0xC3, 1)[0], rf(0xC4, 1)[0])
+    x, x1, x2, x3, x4, xi = (rf(0xE0 + j, 1)[0] for j in range(6))
     us = [rf(0xD0 + j, 1)[0] for j in range(k)]                                   # IPA challenges
-    consts = np.stack([y, zk.halo2._mont_limbs(5, dom._p), zk.halo2._mont_limbs(1, dom._p), beta, gamma])
-    # every chain (a Lagrange column -> coefficients -> extended coset) is owned by one rank; MSMs are sharded over all
-    # NTTs stay single-GPU (north_star): with N > 1 ranks every rank runs every chain and the quotient (replicated), the
-    # MSMs are what is sharded
-    chains = list(range(NCOL + 3 + 3))                              # advice 0..12, lookup A' S' Z_L, permutation Z_P x3
-    mine = chains
-    d_ext = {c: torch.empty((ne, 4), dtype=torch.int64, device="cuda") for c in chains}      # (all resident: the quotient reads all of them)
-    d_zl = torch.empty((n, 4), dtype=torch.int64, device="cuda")
-    d_zp = [torch.empty((n, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
-    d_h = torch.empty((ne, 4), dtype=torch.int64, device="cuda")
-    d_ipa = [torch.empty((n, 4), dtype=torch.int64, device="cuda") for _ in range(2)]
-    # the polynomials create_proof evaluates at x and its rotations (advice / fixed / permutation / lookup / h / random: ~60 queries
-    # at 3 points for this column layout); stand-ins in coefficient form, resident
-    N_EVAL = (45, 10, 5)
-    d_evalsrc = to_dev(e, e.synth.rand_field(sfield, n, 0xE7A1)).unsqueeze(0).repeat(max(N_EVAL), 1, 1).contiguous()
-    x_points = [rf(0xE0 + j, 1)[0] for j in range(3)]
-    d_open = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
-    d_g = torch.empty_like(d_pts_c)
-    prog = quotient_program(NCOL, N_FIXED)
+    p_int = dom._p
+    to_int = lambda v: sum(int(w) << (64 * i) for i, w in enumerate(v.tolist())) * pow(1 << 256, -1, p_int) % p_int
+    mont = lambda v: H._mont_limbs(v % p_int, p_int)
+    w_int, x_int = to_int(dom.omega), to_int(x)
+    x_next, x_prev, x_last = mont(x_int * w_int), mont(x_int * pow(w_int, -1, p_int)), mont(x_int * pow(w_int, -6, p_int))   # omega^last: -(blinding + 1) rows
+    xn = mont(pow(x_int, n, p_int))
+    consts = np.stack([y, mont(5), mont(1), beta, gamma])
+    # ---- the resident coefficient forms, one table [NP, n, 4]: rows grouped by point set, in the order S0 | S2 | S1 | S3 so that
+    # every evaluation point reads ONE contiguous range.  S0 = {x}, S1 = {x, wx}, S2 = {x, w^-1 x}, S3 = {x, wx, w^last x}
+    rot_adv = e.synth.rotated_advice(NCOL)
+    names = ([("inst", c) for c in range(N_INST)] + [("adv", c) for c in range(NCOL) if c not in rot_adv] + [("fixed", c) for c in range(N_FIXED)]
+             + [("random", 0), ("h", 0)] + [("sigma", c) for c in range(N_PERM_COLS)] + [("lk", "S'")])
+    n_s0 = len(names)
+    names += [("lk", "A'")]
+    n_s2 = 1
+    names += [("adv", c) for c in rot_adv] + [("lk", "Z"), ("zp", 2)]
+    n_s1 = len(rot_adv) + 2
+    names += [("zp", 0), ("zp", 1)]
+    n_s3 = 2
+    NP = len(names)
+    row = {nm: i for i, nm in enumerate(names)}
+    sets = [(0, n_s0, [x]), (n_s0 + n_s2, n_s1, [x, x_next]), (n_s0, n_s2, [x, x_prev]), (n_s0 + n_s2 + n_s1, n_s3, [x, x_next, x_last])]
+    d_coef = newbuf(NP, n)
+    for nm in names:                                 # key material / the prover's random polynomial: pre-made, resident
+        if nm[0] in ("fixed", "sigma", "random"):
+            d_coef[row[nm]].copy_(to_dev(e, rf(0xAB00 + row[nm])))
+    d_spoly = to_dev(e, rf(0xBB5))                                                # the argument's blinding polynomial s (RNG: CPU)
+    # ---- chains: every committed Lagrange column -> coefficients (kept) -> this rank's sub-coset of the extended domain
+    chain_names = [("inst", c) for c in range(N_INST)] + [("adv", c) for c in range(NCOL)] + [("lk", "A'"), ("lk", "S'"), ("lk", "Z")] + [("zp", c) for c in range(3)]
+    d_cos = {nm: newbuf(m) for nm in chain_names}
+    d_zl = newbuf(n)
+    d_zp = newbuf(3, n)
+    d_hpart = newbuf(m)
+    d_h = d_hpart if parts == 1 else newbuf(ne)
+    d_q = newbuf(len(sets), n)           # the point sets' folded polynomials
+    d_qprime, d_tmp = newbuf(n), newbuf(n)
+    d_ipa = [newbuf(n) for _ in range(2)]
+    d_S, d_W = torch.zeros((2, n, 4), dtype=torch.int64, device="cuda"), newbuf(n)    # IPA scalar / weight buffers, reused every step
+    prog = e.synth.quotient_program(NCOL, N_FIXED, N_INST)
     main = torch.cuda.current_stream()
     side = main if a.serial else torch.cuda.Stream()
     result = {}
-    phase_ms = {"advice": 0.0, "lookup": 0.0, "permutation": 0.0, "quotient": 0.0, "opening": 0.0}
+    PH = ("advice", "lookup", "permutation", "quotient", "evaluations", "multiopen", "opening")
+    phase_ms = dict.fromkeys(PH, 0.0)
+    cls = {"commit": None, "ipa_full": None, "ipa_small": None}      # MSM totals by size class (read at the class boundaries)
+    cls_sum = {kk: None for kk in cls}
 
-    def chain(c, src, stream):
-        """Lagrange column -> coefficients -> extended coset (only on the rank that owns chain c)"""
-        if c in mine:
-            d_ext[c][:n].copy_(src, non_blocking=True)
-            dom.lagrange_to_coeff(d_ext[c][:n], stream=stream)
-            dom.coeff_to_extended(d_ext[c], stream=stream)
+    def chain(nm, src, stream):
+        """Lagrange column -> coefficients (out of place, kept for the openings) -> this rank's sub-coset"""
+        co = d_coef[row[nm]]
+        dom.lagrange_to_coeff(src, stream=stream, out=co)
+        dom.coeff_to_extended_part(co, d_cos[nm], part, parts, stream=stream)
 
-    collapse_at = {int(x) for x in str(a.ipa_collapse_after).split(",") if x.strip()}
-
+    collapse_at = {int(v) for v in str(a.ipa_collapse_after).split(",") if v.strip()}
     pre = a.precomputed and e.world == 1
     if pre:
         g_lagrange.precompute(a.window_bits)
@@ -362,117 +361,215 @@ def bench_halo2(e):
             return [e.zkdist.msm_sharded(bases, cols[c], montgomery=True, window_bits=a.window_bits, stream=e.st) for c in range(cols.shape[0])]
         return e.zkdist.msm_batch_sharded(bases, cols, montgomery=True, window_bits=a.window_bits, stream=e.st)
 
+    def commit(bases, col):
+        return e.zkdist.msm_sharded(bases, col, montgomery=True, window_bits=a.window_bits, stream=e.st)
+
+    def take_class(name):
+        t = zk.msm_profile_totals(reset=True)
+        if cls_sum[name] is None:
+            cls_sum[name] = dict.fromkeys(t, 0)
+        for kk, v in t.items():
+            cls_sum[name][kk] += v
+
     def step(i, timed_):
         t0 = time.perf_counter()
-        # ---- 1 advice: NTT chains on the side stream beside the batched commitments
+        # ---- 0 + 1 instance and advice columns: NTT chains on the side stream beside one batched commitment call
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            for c in range(N_INST):
+                chain(("inst", c), d_lag[c], side.cuda_stream)
             for c in range(NCOL):
-                chain(c, d_cols[c], side.cuda_stream)
-        result["commitments"] = commit_batch(g_lagrange, d_cols)
+                chain(("adv", c), d_lag[N_INST + c], side.cuda_stream)
+        result["commitments"] = commit_batch(g_lagrange, d_lag)
+        if "prof" not in result:
+            result["prof"] = zk.msm_last_profile()
         main.wait_stream(side)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        # ---- 2 lookup
-        commit_batch(g_lagrange, d_lookup[2:4])
-        zk.halo2.lookup_product(sfield, d_lookup[0], d_lookup[1], d_lookup[2], d_lookup[3], beta, gamma, d_zl, stream=e.st)
+        # ---- 2 lookup: the permuted columns
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            chain(NCOL, d_lookup[2], side.cuda_stream)
-            chain(NCOL + 1, d_lookup[3], side.cuda_stream)
-            chain(NCOL + 2, d_zl, side.cuda_stream)
-        e.zkdist.msm_sharded(g_lagrange, d_zl, montgomery=True, window_bits=a.window_bits, stream=e.st)
+            chain(("lk", "A'"), d_lookup[2], side.cuda_stream)
+            chain(("lk", "S'"), d_lookup[3], side.cuda_stream)
+        commit_batch(g_lagrange, d_lookup[2:4])
         main.wait_stream(side)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        # ---- 3 permutation: chunk c + 1 continues from the last value of chunk c
+        # ---- 3 permutation: chunk c + 1 continues from the last value of chunk c; columns = 13 advice + 3 instance
         z_first = None
-        pcols = [d_cols[c % NCOL] for c in range(N_PERM_COLS)]
+        pcols = [d_lag[N_INST + c] for c in range(NCOL)] + [d_lag[c] for c in range(N_INST)]
         for c in range(3):
             lo, hi = c * PERM_CHUNK, min(N_PERM_COLS, (c + 1) * PERM_CHUNK)
-            z_first = zk.halo2.permutation_product(sfield, pcols[lo:hi], d_sigma[lo:hi], beta, gamma, delta, k, d_zp[c], first_column_index=lo,
-                                                   z_first=z_first, stream=e.st)
+            z_first = H.permutation_product(sfield, pcols[lo:hi], d_sigma[lo:hi], beta, gamma, delta, k, d_zp[c], first_column_index=lo,
+                                            z_first=z_first, stream=e.st)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             for c in range(3):
-                chain(NCOL + 3 + c, d_zp[c], side.cuda_stream)
-        commit_batch(g_lagrange, torch.stack(d_zp))
+                chain(("zp", c), d_zp[c], side.cuda_stream)
+        commit_batch(g_lagrange, d_zp)
         main.wait_stream(side)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
-        # ---- 4 quotient
-        e.zkdist.msm_sharded(g_coeff, d_rand, montgomery=True, window_bits=a.window_bits, stream=e.st)
-        ext_cols = [d_ext[c] for c in range(NCOL)] + d_fixed_ext + [d_ext[NCOL + c] for c in range(6)]
-        zk.halo2.evaluate_expression(sfield, prog, ext_cols, consts, ext, 1 << (ext - k), d_h, stream=e.st)
-        dom.divide_by_vanishing_poly(d_h, stream=e.st)
-        dom.extended_to_coeff(d_h, stream=e.st)
-        commit_batch(g_coeff, d_h.view(N_H_PIECES, n, 4))
+        # ---- 4 lookup product
+        H.lookup_product(sfield, d_lookup[0], d_lookup[1], d_lookup[2], d_lookup[3], beta, gamma, d_zl, stream=e.st)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            chain(("lk", "Z"), d_zl, side.cuda_stream)
+        commit(g_lagrange, d_zl)
+        main.wait_stream(side)
         torch.cuda.synchronize()
         t4 = time.perf_counter()
-        # ---- 5 opening: the evaluations at x, omega x, omega^-1 x (one batched launch per point), then the inner-product argument
-        # (the combined polynomial stands in: one of the coefficient vectors)
-        for cnt, xp in zip(N_EVAL, x_points):
-            zk.halo2.eval_polynomials(sfield, d_evalsrc[:cnt], xp, stream=e.st)
-        for cnt in N_EVAL:                       # multiopen: fold each point set's polynomials with powers of x_1 (Horner)
-            for q in range(1, cnt):
-                zk.halo2.vec_muladd(sfield, d_open, d_evalsrc[q], x_points[0], stream=e.st)
-        d_ipa[0].copy_(d_h[:n])
-        d_ipa[1].copy_(d_ext[0][:n])
+        # ---- 5 vanishing argument's random polynomial, 6 quotient
+        commit(g_coeff, d_coef[row[("random", 0)]])
+        ext_cols = ([d_cos[("adv", c)] for c in range(NCOL)] + d_fixed_cos + [d_cos[("lk", "A'")], d_cos[("lk", "S'")], d_cos[("lk", "Z")]]
+                    + [d_cos[("zp", c)] for c in range(3)] + [d_cos[("inst", c)] for c in range(N_INST)])
+        H.evaluate_expression(sfield, prog, ext_cols, consts, ext - (parts.bit_length() - 1), rsc, d_hpart, stream=e.st)
+        dom.divide_by_vanishing_poly_part(d_hpart, part, parts, stream=e.st)
+        if parts > 1:
+            e.zkdist.gather_parts(d_hpart, d_h, stream=main)
+        dom.extended_to_coeff(d_h, stream=e.st)
+        pieces = d_h.view(N_H_PIECES, n, 4)
+        commit_batch(g_coeff, pieces)
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        # ---- 7 evaluations: h(X) = sum_i x^(n i) h_i, then every committed polynomial at x and at its rotations
+        hrow = d_coef[row[("h", 0)]]
+        H.vec_muladd(sfield, pieces[N_H_PIECES - 1], pieces[N_H_PIECES - 2], xn, stream=e.st, out=hrow)
+        for q in range(N_H_PIECES - 3, -1, -1):
+            H.vec_muladd(sfield, hrow, pieces[q], xn, stream=e.st)
+        result["evals"] = [H.eval_polynomials(sfield, d_coef, x, stream=e.st),
+                           H.eval_polynomials(sfield, d_coef[sets[1][0]:], x_next, stream=e.st),
+                           H.eval_polynomials(sfield, d_coef[sets[2][0]:sets[2][0] + sets[2][1]], x_prev, stream=e.st),
+                           H.eval_polynomials(sfield, d_coef[sets[3][0]:], x_last, stream=e.st)]
+        t6 = time.perf_counter()
+        # ---- 8 multiopen
+        for s_, (first, cnt, pts) in enumerate(sets):
+            if cnt == 1:
+                d_q[s_].copy_(d_coef[first])
+            else:
+                H.vec_muladd(sfield, d_coef[first], d_coef[first + 1], x1, stream=e.st, out=d_q[s_])
+                for q in range(2, cnt):
+                    H.vec_muladd(sfield, d_q[s_], d_coef[first + q], x1, stream=e.st)
+        for s_, (first, cnt, pts) in enumerate(sets):          # q' = q' x_2 + (set polynomial / prod (X - point))
+            dst = d_qprime if s_ == 0 else d_tmp
+            H.kate_division(sfield, d_q[s_], pts[0], out=dst, stream=e.st)
+            for pt in pts[1:]:
+                H.kate_division(sfield, dst, pt, stream=e.st)
+            if s_:
+                H.vec_muladd(sfield, d_qprime, d_tmp, x2, stream=e.st)
+        commit(g_coeff, d_qprime)
+        result["q_evals"] = H.eval_polynomials(sfield, d_q, x3, stream=e.st)
+        for s_ in range(len(sets)):                             # p = q' x_4^4 + ... : one Horner step per set
+            H.vec_muladd(sfield, d_qprime, d_q[s_], x4, stream=e.st)
+        torch.cuda.synchronize()
+        t7 = time.perf_counter()
+        if timed_:
+            take_class("commit")
+        # ---- 9 opening: the inner-product argument on p at x_3
+        commit(g_coeff, d_spoly)
+        H.vec_muladd(sfield, d_spoly, d_qprime, xi, stream=e.st, out=d_ipa[0])            # p' = s xi + p
+        result["v"] = H.eval_polynomial(sfield, d_ipa[0], x3, stream=e.st)               # (p'[0] -= v: one element, host side upstream)
+        H.vec_powers(sfield, d_ipa[1], x3, stream=e.st)                                  # b
+        if timed_:
+            take_class("commit")
         if a.ipa == "fold":       # upstream's literal structure: collapse the generators every round
+            d_g = result.setdefault("d_g", torch.empty_like(d_pts_c))
             d_g.copy_(d_pts_c)
-            ipa = zk.halo2.IpaProver(curve, d_ipa[0], d_ipa[1], d_g, stream=e.st)
+            ipa = H.IpaProver(curve, d_ipa[0], d_ipa[1], d_g, stream=e.st)
         else:                     # L, R over the resident SRS with challenge-weighted scalars: no generator is ever folded
-            ipa = zk.halo2.IpaProverVirtual(curve, d_ipa[0], d_ipa[1], g_coeff, lambda shape: torch.zeros(shape, dtype=torch.int64, device="cuda"),
-                                            stream=e.st)
+            ipa = H.IpaProverVirtual(curve, d_ipa[0], d_ipa[1], g_coeff, lambda shape: torch.zeros(shape, dtype=torch.int64, device="cuda"),
+                                     stream=e.st, buffers=(d_S, d_W))
+        small = False
         for j in range(k):
             ipa.round(sharded=e.world > 1)
             ipa.fold(us[j])
             if a.ipa == "collapse" and (j + 1) in collapse_at and j + 1 < k:
                 ipa.collapse(sharded=e.world > 1)
+                if timed_ and not small:
+                    take_class("ipa_full")
+                    small = True
         ipa.free()
         torch.cuda.synchronize()
-        t5 = time.perf_counter()
         if timed_:
-            for name, dt in zip(phase_ms, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+            take_class("ipa_small" if small else "ipa_full")
+        t8 = time.perf_counter()
+        if timed_:
+            for name, dt in zip(PH, (t1 - t0, (t2 - t1) + (t4 - t3), t3 - t2, t5 - t4, t6 - t5, t7 - t6, t8 - t7)):
                 phase_ms[name] += dt * 1e3
 
     elapsed = timed(e, step)
+    # the library totals were drained class by class inside the steps: rebuild the whole-run sums for rooflines()
+    tot = dict.fromkeys(e.msm_tot, 0)
+    for cs in cls_sum.values():
+        if cs:
+            for kk, v in cs.items():
+                tot[kk] += v
+    for kk, v in e.msm_tot.items():
+        tot[kk] += v
+    e.msm_tot = tot
     if e.rank == 0:
-        prof = zk.msm_last_profile()
-        m = e.msm_tot
-        n_msm = NCOL + 3 + 3 + 1 + N_H_PIECES
+        prof = result["prof"]
+        mm = e.msm_tot
+        n_chain = len(chain_names)
+        n_commit = NLAG + 2 + 3 + 1 + 1 + N_H_PIECES + 1 + 1          # columns, A' S', Z_P x3, Z_L, random, h pieces, q', s
+        n_eval = NP + n_s1 + n_s3 + n_s2 + n_s3
+        n_kate = sum(len(pts) for _, _, pts in sets)
         line = base_line(e, n * a.steps / elapsed, elapsed,
-                         "halo2 create_proof device work-list, 2^%d rows, the reference circuit's column layout (BASELINE configs[2]): advice 13 x (commit + l2c + c2e) ; "
-                         "lookup 3 commits + product + 3 NTT chains ; permutation 3 products + 3 commits + 3 NTT chains ; quotient: random-poly commit, "
-                         "%d-op expression over 27 extended columns, divide by Z_H, extended_to_coeff, 8 h-piece commits ; opening: 60 evaluations at 3 points + the multiopen folds, %d-round IPA "
-                         "(2 MSMs + 2 inner products + 3 folds per round; generators %s)" % (
-                             k, len(prog), k, {"fold": "folded every round", "virtual": "never folded: every MSM over the SRS",
-                                               "collapse": "materialised after round(s) %s by zk_ipa_collapse_device" % a.ipa_collapse_after}[a.ipa]),
-                         {"rows_per_step": n, "msm_curve": curve, "msm_points": n, "msm_windows_done": 16, "msm_windows": 16,
-                          "window_bits": 16, "columns": NCOL, "full_size_msms_per_step": n_msm, "ntt_2p%d_per_step" % k: 19, "ntt_2p%d_per_step" % ext: 20,
+                         "halo2 create_proof device work-list, 2^%d rows, the reference circuit's column layout (BASELINE configs[2]): %d instance + %d advice commits "
+                         "(Lagrange basis) + %d NTT chains (l2c kept + coeff_to_extended) ; lookup: 2 + 1 commits, product ; permutation: 3 products + 3 commits ; "
+                         "random-poly commit ; quotient: %d-op expression over %d extended columns, divide by Z_H, extended_to_coeff, %d h-piece commits ; "
+                         "%d evaluations at 4 points ; multiopen: 4 point sets (x_1 folds, %d kate divisions, x_2 fold, q' commit, evaluations at x_3, x_4 fold) ; "
+                         "%d-round IPA on p (s commit, p' = s xi + p, b = powers of x_3 ; 2 MSMs + 2 inner products + 3 folds per round; generators %s)" % (
+                             k, N_INST, NCOL, n_chain, len(prog), NCOL + N_FIXED + 6 + N_INST, N_H_PIECES, n_eval, n_kate, k,
+                             {"fold": "folded every round", "virtual": "never folded: every MSM over the SRS",
+                              "collapse": "materialised after round(s) %s by zk_ipa_collapse_device" % a.ipa_collapse_after}[a.ipa]),
+                         {"rows_per_step": n, "msm_curve": curve, "msm_points": n, "msm_windows_done": prof["windows_done"], "msm_windows": prof["windows_total"],
+                          "window_bits": prof["window_bits"], "columns": NCOL, "instance_columns": N_INST, "full_size_msms_per_step": n_commit,
+                          "ntt_2p%d_per_step" % k: n_chain, "ntt_2p%d_per_step" % ext: n_chain + 1, "kate_divisions_per_step": n_kate, "evaluations_per_step": n_eval,
+                          "extended_coset_parts": parts,
                           "streams": "one (serial)" if a.serial else "MSM batches on two library streams + NTT chains on a third",
-                          "not_in_list": "RNG, transcript, the lookup argument's sort (CPU)"})
+                          "not_in_list": "RNG (blinding, random polynomials), transcript, the lookup argument's sort (CPU)"})
+        if e.world > 1:
+            line["config"]["parallelism"] = "msm-window-shard x%d + all_gather ; extended coset in %d sub-cosets + all_gather of h" % (e.world, parts)
         line["phases_ms"] = {kk: v / a.steps for kk, v in phase_ms.items()}
-        line["msm_ms_mean_all_sizes"] = m["device_ms"] / max(1, m["msms"])
-        line["msms_per_step"] = m["msms"] / a.steps
+        line["msms_per_step"] = mm["msms"] / a.steps
+        by_class = {}
+        for name, cs in cls_sum.items():
+            if cs and cs["msms"]:
+                by_class[name] = {"msms_per_step": cs["msms"] / a.steps, "launches_per_step": cs["launches"] / a.steps,
+                                  "device_ms_per_msm": cs["device_ms"] / cs["msms"], "host_tail_ms_per_msm": cs["host_tail_ms"] / cs["msms"],
+                                  "accumulate_kernel_us_per_launch": cs["accumulate_kernel_ms"] / cs["launches"] * 1e3}
+        line["msm_by_class"] = by_class
+        cm = cls_sum["commit"]
+        if cm and cm["msms"]:     # BASELINE metric, second half: MSM Mop/s of the full-size (2^k-point, dense) commitments inside the work-list
+            line["msm_mops"] = n * cm["msms"] / ((cm["device_ms"] + cm["host_tail_ms"]) * 1e-3) / 1e6
+            line["msm_ms"] = (cm["device_ms"] + cm["host_tail_ms"]) / cm["msms"]
         line["ntt_kernel_ms_per_step"] = e.ntt_tot["kernel_ms"] / a.steps
-        line["accumulate_kernel_ms_per_step"] = m["accumulate_kernel_ms"] / a.steps
+        line["accumulate_kernel_ms_per_step"] = mm["accumulate_kernel_ms"] / a.steps
         if not a.no_cpu_baseline and e.world == 1:
-            line["cpu_baseline"] = cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, cols_host[0], result["commitments"][0], sum(1 for o in prog if o[0] in ("mul", "scale")))
+            counts = {"msm": n_commit, "ntt_k": n_chain, "ntt_ext": n_chain + 1, "evals": n_eval, "kate": n_kate,
+                      "folds": NP - len(sets) + len(sets) - 1 + len(sets) + N_H_PIECES - 1 + 1,
+                      "expr_muls": sum(1 for o in prog if o[0] in ("mul", "scale"))}
+            line["cpu_baseline"] = cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, lag_host[0], result["commitments"][0], counts)
         roofs = rooflines(e, "halo2_2p%d" % k)
-        if "msm_accumulate_kernel" in roofs:     # the IPA's small MSMs are in the totals: per-launch figures are means over all sizes
-            roofs["msm_accumulate_kernel"]["note"] += "; launches include the 2 x %d shrinking MSMs of the IPA (means over all sizes)" % k
-        line["config"].pop("msm_curve")
+        if "msm_accumulate_kernel" in roofs:     # per-launch figures of the full-size commitments (the IPA's launches are listed in msm_by_class)
+            r = roofs["msm_accumulate_kernel"]
+            if cm and cm["launches"]:
+                ach = cm["algorithmic_bytes"] / (cm["accumulate_kernel_ms"] * 1e-3) / 1e9
+                r.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS, "launches": cm["launches"], "msms": cm["msms"],
+                          "avg_launch_us": cm["accumulate_kernel_ms"] / cm["launches"] * 1e3,
+                          "algorithmic_bytes_per_launch": cm["algorithmic_bytes"] / cm["launches"]})
+                r["note"] += "; per-launch figures = the %d full-size commitment MSMs of a step (up to 4 scalar vectors per launch); kernel_ms_total = all classes" % n_commit
         emit(e, line, roofs)
 
 
-def cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, col0, gpu_commit0, n_expr_muls):
+def cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, col0, gpu_commit0, counts):
     """The oracle ('port': CPU restatements of halo2_proofs 0.2 best_multiexp -- chunk per thread over ALL host cores -- ,
     best_fft, and per-element field / curve arithmetic) timed on this box on a bounded sample of the same work-list:
-    ONE commitment, ONE iNTT 2^k, ONE NTT 2^(k+3), 2^16 field products (grand products / expression), 2^12 point
-    multiplications (the IPA generator fold); the step is assembled from the counts of each kind, with perfect scaling
-    over the cores assumed for the per-element work.  ark-ec's window-parallel Pippenger is timed beside the chunked
-    one and the FASTER MSM is used.  Also a last bit-exact check of the GPU's first commitment."""
+    ONE commitment (both reference MSM algorithms, the faster is used), ONE best_fft at 2^k and ONE at 2^(k+3) (all cores, and one
+    thread for the scaling figure), 2^20 field products on one thread, 2^17 point multiplications on all cores (and 2^10 on one
+    thread); the step is assembled from the counts of each kind, with perfect scaling over the cores assumed for the per-element
+    work.  Also a last bit-exact check of the GPU's first commitment."""
     from oracle import zk_oracle as orc
     np, zk = e.np, e.zk
     cores = os.cpu_count() or 1
@@ -490,34 +587,45 @@ def cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, col0, gpu_commit0, n_exp
     t0 = time.perf_counter()
     orc.halo2_best_fft(sfield, col0, w, k, threads=cores)
     t_n = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.halo2_best_fft(sfield, col0, w, k, threads=1)
+    t_n1 = time.perf_counter() - t0
     big = e.synth.rand_field(sfield, 1 << ext, 0xF00D)
     t0 = time.perf_counter()
     orc.halo2_best_fft(sfield, big, w_ext, ext, threads=cores)
     t_e = time.perf_counter() - t0
     t0 = time.perf_counter()
-    orc.to_mont(sfield, col0[: 1 << 16])                       # one Montgomery product per element, one thread
-    t_mul = (time.perf_counter() - t0) / (1 << 16)
-    ks = e.synth.scalars_for(curve, 1 << 12, 77)
+    orc.to_mont(sfield, col0)                                  # one Montgomery product per element, one thread, 2^k elements
+    t_mul = (time.perf_counter() - t0) / n
+    ks1 = e.synth.scalars_for(curve, 1 << 10, 78)
     t0 = time.perf_counter()
-    orc.fixed_base_mul(curve, ks, threads=cores)               # 255-bit double-and-add per point, all cores
-    t_pmul = (time.perf_counter() - t0) / (1 << 12)
+    orc.fixed_base_mul(curve, ks1, threads=1)                  # 255-bit double-and-add per point, one thread
+    t_pmul1 = (time.perf_counter() - t0) / (1 << 10)
+    ks = e.synth.scalars_for(curve, 1 << 17, 77)
+    t0 = time.perf_counter()
+    orc.fixed_base_mul(curve, ks, threads=cores)               # ... all cores, 2^17 points (>= 512 per thread)
+    t_pmul = (time.perf_counter() - t0) / (1 << 17)
     t_msm = min(t_h2, t_ark)
-    n_msm, n_ntt_k, n_ntt_e = NCOL + 3 + 3 + 1 + N_H_PIECES, 19, 20
     muls_products = n * (4 * 8 + 3 * (4 * PERM_CHUNK + 8))      # factors, batched inversion, scan: lookup + three permutation chunks
-    muls_expr = (1 << ext) * n_expr_muls                       # the products of the quotient program, at every row of the extended domain
-    muls_eval = 2 * 60 * n                                      # evaluations (Horner) + multiopen folds: one product per coefficient each
-    t_field = (muls_products + muls_expr + muls_eval) * t_mul / cores
+    muls_expr = (1 << ext) * counts["expr_muls"]               # the products of the quotient program, at every row of the extended domain
+    muls_open = n * (counts["evals"] + counts["folds"] + counts["kate"] + 2)   # Horner evaluations, folds, kate_division, b: one product per coefficient each
+    t_field = (muls_products + muls_expr + muls_open) * t_mul / cores
     # IPA: MSMs of 2 * (n/2 + n/4 + ...) = 2n points ~ two full MSMs; n point multiplications for the generator folds
     t_ipa = 2 * t_msm + n * t_pmul
-    t_step = n_msm * t_msm + n_ntt_k * t_n + n_ntt_e * t_e + t_field + t_ipa
+    t_step = counts["msm"] * t_msm + counts["ntt_k"] * t_n + counts["ntt_ext"] * t_e + t_field + t_ipa
     ok = bool((zk.point_to_affine(curve, gpu_commit0) == exp).all() and (exp == exp_ark).all())
     return {"value": n / t_step, "unit": "constraints/s", "cores": cores, "kind": "port",
-            "sample": "best_multiexp 2^%d (halo2 chunk-per-thread, %d threads: %.3f s; ark window-parallel, %d threads: %.3f s; faster one used) ; best_fft 2^%d %.3f s, "
-                      "2^%d %.3f s (%d threads) ; field product %.0f ns (one thread) ; point multiplication %.1f us per point on %d threads ; "
+            "sample": "best_multiexp 2^%d (halo2 chunk-per-thread, %d threads: %.3f s; ark window-parallel, %d threads: %.3f s; faster one used) ; best_fft 2^%d %.3f s "
+                      "(%d threads; %.3f s on one: x%.1f -- upstream's serial bit-reversal and twiddle table bound it), 2^%d %.3f s ; field product %.0f ns (one thread, 2^%d products) ; "
+                      "point multiplication %.0f us on one thread, %.2f us per point on %d threads (2^17 points) ; "
                       "step = %d MSMs + %d + %d FFTs + %.2g products / %d cores + IPA (2 MSM + 2^%d point multiplications) = %.2f s"
-                      % (k, cores, t_h2, ark_threads, t_ark, k, t_n, ext, t_e, cores, t_mul * 1e9, t_pmul * 1e6, cores, n_msm, n_ntt_k, n_ntt_e,
-                         muls_products + muls_expr, cores, k, t_step),
-            "msm_mops": n / t_msm / 1e6, "msm_s": {"halo2_chunked": t_h2, "ark_window_parallel": t_ark}, "gpu_result_matches": ok}
+                      % (k, cores, t_h2, ark_threads, t_ark, k, t_n, cores, t_n1, t_n1 / t_n, ext, t_e, t_mul * 1e9, k, t_pmul1 * 1e6, t_pmul * 1e6, cores,
+                         counts["msm"], counts["ntt_k"], counts["ntt_ext"], muls_products + muls_expr + muls_open, cores, k, t_step),
+            "msm_mops": n / t_msm / 1e6, "msm_s": {"halo2_chunked": t_h2, "ark_window_parallel": t_ark},
+            "fft_s": {"2p%d_all_cores" % k: t_n, "2p%d_one_thread" % k: t_n1, "2p%d_all_cores" % ext: t_e},
+            "point_mul_us": {"one_thread": t_pmul1 * 1e6, "per_point_all_cores": t_pmul * 1e6},
+            "step_s": {"msm": counts["msm"] * t_msm, "fft": counts["ntt_k"] * t_n + counts["ntt_ext"] * t_e, "field": t_field, "ipa": t_ipa},
+            "gpu_result_matches": ok}
 
 
 # ---------------------------------------------------------------------------------------------------- column (configs[1])

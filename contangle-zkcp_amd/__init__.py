@@ -33,7 +33,7 @@ EXPORTS = [
     "zk_point_add", "zk_point_to_affine", "zk_fixed_base_mul_device", "zk_vec_op_device", "zk_groth16_witness_map_device",
     "zk_fixed_base_msm_device", "zk_ntt_extend_device", "zk_init_devices", "zk_device_count", "zk_msm_submit", "zk_msm_collect",
     "zk_msm_batch_device", "zk_ntt_configure", "zk_msm_profile_totals", "zk_ntt_profile_enable", "zk_ntt_profile_read",
-    "zk_field_modulus", "zk_vec_scale_periodic_device", "zk_bases_refresh", "zk_bases_precompute",
+    "zk_field_modulus", "zk_vec_scale_periodic_device", "zk_bases_refresh", "zk_bases_precompute", "zk_ntt_oop_device",
 ]
 
 
@@ -54,6 +54,7 @@ class MsmOpts(ctypes.Structure):
 MSM_FLAG_NO_HOT_HELP = 1
 MSM_FLAG_SLICE_REDUCE = 2
 MSM_FLAG_PRECOMPUTED = 4
+MSM_FLAG_DEVICE_PARTIALS = 8
 
 
 class NttOpts(ctypes.Structure):
@@ -115,6 +116,7 @@ def load(path=None):
     lib.zk_ntt_device.argtypes = [i32, vp, ctypes.c_uint32, vp, i32, vp]
     lib.zk_ntt_coset_device.argtypes = [i32, vp, ctypes.c_uint32, vp, i32, vp, vp, vp]
     lib.zk_ntt_extend_device.argtypes = [i32, vp, ctypes.c_uint32, ctypes.c_uint32, vp, i32, vp, vp, vp]
+    lib.zk_ntt_oop_device.argtypes = [i32, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, i32, vp, vp, vp]
     lib.zk_coset_mul.argtypes = [i32, vp, ctypes.c_uint32, vp]
     lib.zk_coset_mul_device.argtypes = [i32, vp, ctypes.c_uint32, vp, vp]
     lib.zk_field_root_of_unity.argtypes = [i32, ctypes.c_uint32, vp]
@@ -290,7 +292,7 @@ class Bases:
 
 
 def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len=0, big_threshold=0, waves_per_simd=0,
-             no_hot_help=False, base_offset=0, slice_reduce=False, precomputed=False):
+             no_hot_help=False, base_offset=0, slice_reduce=False, precomputed=False, device_partials=False):
     o = MsmOpts()
     o.window_bits = window_bits
     if windows is not None:
@@ -301,7 +303,7 @@ def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len
     o.big_threshold = big_threshold
     o.waves_per_simd = waves_per_simd
     o.flags = ((MSM_FLAG_NO_HOT_HELP if no_hot_help else 0) | (MSM_FLAG_SLICE_REDUCE if slice_reduce else 0)
-               | (MSM_FLAG_PRECOMPUTED if precomputed else 0))
+               | (MSM_FLAG_PRECOMPUTED if precomputed else 0) | (MSM_FLAG_DEVICE_PARTIALS if device_partials else 0))
     o.base_offset = base_offset
     return o
 
@@ -385,13 +387,26 @@ def ntt_profile_read():
     return {k: getattr(t, k) for k, _ in NttTotals._fields_}
 
 
-def ntt(field, a, omega, scale_by_n_inv=False, stream=0, coset_pre=None, coset_post=None, device=False, in_log=None):
+def ntt(field, a, omega, scale_by_n_inv=False, stream=0, coset_pre=None, coset_post=None, device=False, in_log=None, src=None):
     """In-place size-2^k DFT with root `omega` (Montgomery); numpy (host, returns a new array) or torch GPU tensor.
     coset_pre / coset_post: a[i] *= g^i before / a[k] *= g^k after the transform, fused into the first / last pass on
     device buffers.  device=True treats a numpy array as a device buffer (only meaningful under the CPU test emulator).
-    in_log: the input is a[:2^in_log] zero-extended to len(a) (halo2 coeff_to_extended); the padding is never read."""
+    in_log: the input is a[:2^in_log] zero-extended to len(a) (halo2 coeff_to_extended); the padding is never read.
+    src (device buffers): read the input from there instead and leave it untouched -- the result lands in `a` (out of place)."""
     lib = load()
     om = _np64(omega)
+    if src is not None:
+        n = int(a.shape[0])
+        log_n = n.bit_length() - 1
+        assert n == 1 << log_n
+        li = log_n if in_log is None else int(in_log)
+        assert int(src.shape[0]) >= 1 << li
+        gp = _np64(coset_pre) if coset_pre is not None else None
+        gq = _np64(coset_post) if coset_post is not None else None
+        _check(lib.zk_ntt_oop_device(field_id(field), _ptr(src), _ptr(a), log_n, li, _ptr(om), int(scale_by_n_inv),
+                                     _ptr(gp) if gp is not None else None, _ptr(gq) if gq is not None else None,
+                                     ctypes.c_void_p(stream)), "zk_ntt_oop_device")
+        return a
     if isinstance(a, np.ndarray) and not device and in_log is None:
         buf = _np64(a).copy()
         n = buf.shape[0]

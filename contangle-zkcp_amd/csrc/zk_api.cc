@@ -106,13 +106,14 @@ MsmTuning tuning_from(const zk_msm_opts* o) {
     t.no_hot_help = (o->flags & ZK_MSM_FLAG_NO_HOT_HELP) != 0;
     t.slice_reduce = (o->flags & ZK_MSM_FLAG_SLICE_REDUCE) != 0;
     t.precomputed = (o->flags & ZK_MSM_FLAG_PRECOMPUTED) != 0;
+    t.device_partials = (o->flags & ZK_MSM_FLAG_DEVICE_PARTIALS) != 0;
     t.base_offset = o->base_offset > 0 ? (uint64_t)o->base_offset : 0;
     return t;
 }
 
 void free_job(MsmJob& j) {
     for (DevBuf* b : {&j.scalars_in, &j.hot, &j.counts, &j.digits, &j.blockcnt, &j.stage_idx, &j.stage_low, &j.queue, &j.seg_out, &j.subacc, &j.sorted,
-                      &j.buckets, &j.part_a, &j.part_b})
+                      &j.buckets, &j.part_a, &j.part_b, &j.part_std})
         ws_free(*b);
     if (j.host_partials) hipHostFree(j.host_partials);
     j.host_partials = nullptr;
@@ -914,6 +915,31 @@ API int zk_ntt_extend_device(zk_field_t f, void* a, uint32_t log_n, uint32_t log
     });
     return ZK_ERR_INVALID_ARG;
 }
+API int zk_ntt_oop_device(zk_field_t f, const void* src, void* dst, uint32_t log_n, uint32_t log_in, const void* omega, int scale, const void* g_pre,
+                          const void* g_post, void* stream) {
+    if (!src || !dst || !omega || !aligned16(src) || !aligned16(dst) || log_in > log_n || log_n > 30) return ZK_ERR_INVALID_ARG;
+    if (src == dst) return zk_ntt_extend_device(f, dst, log_n, log_in, omega, scale, g_pre, g_post, stream);
+    {   // the buffers must not overlap: the first pass reads src while later tiles of the same pass may already write dst
+        const uintptr_t s0 = (uintptr_t)src, s1 = s0 + ((uintptr_t)32 << log_in), d0 = (uintptr_t)dst, d1 = d0 + ((uintptr_t)32 << log_n);
+        if (s0 < d1 && d0 < s1) return ZK_ERR_INVALID_ARG;
+    }
+    DEVICE_ENTRY(dst);
+    FIELD_SWITCH(f, {
+        if (log_n > (uint32_t)F::TWO_ADICITY) return ZK_ERR_INVALID_ARG;
+        Fe<F> w, gp, gq;
+        host_load(w, omega);
+        if (g_pre) host_load(gp, g_pre);
+        if (g_post) host_load(gq, g_post);
+        if (log_n > 0 && log_in == 0) {   // a single coefficient (in_log = 0 means "all" to the pass kernel): pad explicitly, then in place
+            HIP_TRY(hipMemcpyAsync(dst, src, sizeof(Fe<F>), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            HIP_TRY(hipMemsetAsync((Fe<F>*)dst + 1, 0, (((size_t)1 << log_n) - 1) * sizeof(Fe<F>), (hipStream_t)stream));
+            return ntt_run<F>(dc, (int)f, (Fe<F>*)dst, log_n, w, scale, (hipStream_t)stream, g_pre ? &gp : nullptr, g_post ? &gq : nullptr, log_in);
+        }
+        return ntt_run<F>(dc, (int)f, (Fe<F>*)dst, log_n, w, scale, (hipStream_t)stream, g_pre ? &gp : nullptr, g_post ? &gq : nullptr, log_in,
+                          (const Fe<F>*)src);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
 API int zk_coset_mul_device(zk_field_t f, void* a, uint32_t log_n, const void* gm, void* stream) {
     if (!a || !gm || !aligned16(a)) return ZK_ERR_INVALID_ARG;
     DEVICE_ENTRY(a);
@@ -1124,7 +1150,17 @@ API int zk_vec_muladd_device(zk_field_t f, void* a, const void* b, uint64_t n, c
     FIELD_SWITCH(f, {
         Fe<F> ss;
         host_load(ss, s);
-        return vec_muladd_run<F>((Fe<F>*)a, (const Fe<F>*)b, n, ss, (hipStream_t)stream);
+        return vec_muladd_run<F>((Fe<F>*)a, (const Fe<F>*)a, (const Fe<F>*)b, n, ss, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_vec_muladd_to_device(zk_field_t f, void* out, const void* a, const void* b, uint64_t n, const void* s, void* stream) {
+    if (!s || (n && (!out || !a || !b || !aligned16(out) || !aligned16(a) || !aligned16(b)))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(out);
+    FIELD_SWITCH(f, {
+        Fe<F> ss;
+        host_load(ss, s);
+        return vec_muladd_run<F>((Fe<F>*)out, (const Fe<F>*)a, (const Fe<F>*)b, n, ss, (hipStream_t)stream);
     });
     return ZK_ERR_INVALID_ARG;
 }
@@ -1139,6 +1175,30 @@ API int zk_poly_eval_batch_device(zk_field_t f, const void* c, uint64_t n, uint3
         Fe<F> xx;
         host_load(xx, x);
         return poly_eval_run<F>(dc, (const Fe<F>*)c, n, count, stride_elems, xx, (int)f, out_host, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_vec_powers_device(zk_field_t f, void* out, uint64_t n, const void* x, void* stream) {
+    if (!x || (n && (!out || !aligned16(out)))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(out);
+    FIELD_SWITCH(f, {
+        Fe<F> xx;
+        host_load(xx, x);
+        return vec_powers_run<F>(dc, (Fe<F>*)out, n, xx, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_kate_division_device(zk_field_t f, const void* a, void* q, uint64_t n, const void* x, void* stream) {
+    if (!x || (n && (!a || !q || !aligned16(a) || !aligned16(q)))) return ZK_ERR_INVALID_ARG;
+    if (a != q) {
+        const uintptr_t a0 = (uintptr_t)a, q0 = (uintptr_t)q, len = (uintptr_t)n * 32;
+        if (a0 < q0 + len && q0 < a0 + len) return ZK_ERR_INVALID_ARG;   // in place or disjoint
+    }
+    DEVICE_ENTRY(q);
+    FIELD_SWITCH(f, {
+        Fe<F> xx;
+        host_load(xx, x);
+        return kate_division_run<F>(dc, (const Fe<F>*)a, (Fe<F>*)q, n, xx, (hipStream_t)stream);
     });
     return ZK_ERR_INVALID_ARG;
 }

@@ -200,30 +200,34 @@ ZK_HD bool fe29_is_kp(const Fe29<P>& a, uint32_t k) {
     for (int i = 0; i < F29<P>::L; i++) o |= t.v[i] ^ F29<P>::KP[k][i];
     return o == 0;
 }
-// canonical representative in [0, p): strict limbs.  Slow (conversion / rare paths only); value must be < 20 p.
+// canonical representative in [0, p): strict limbs.  Conversion / rare paths only; value must be < 20 p.
+// Branch-free: t -= 16p, 8p, 4p, 2p, p in turn, each kept only if it did not borrow out of the top limb (compile-time rows of
+// KP, no data-dependent control flow).  Round 2's form -- "for k = 19 .. 1: lexicographic compare with KP[k], early exits,
+// subtract and break" -- is correct C++ (host and emulator agree with Python) but, inlined behind the LDS scan of
+// msm_axis_weighted_kernel with one active lane, gfx950 code generation returned a difference whose middle limbs were
+// 2^29 - 1 for BN254's Fq (the borrow chain ran against stale operands: profiles/r03_a_bn254_device_partials.txt shows the
+// product stage equal and this stage differing on the device only).  tests: test_msm_device_side_partial_conversion.
 template <class P>
 ZK_HD void fe29_canon(Fe29<P>& r, const Fe29<P>& a) {
+    constexpr int L = F29<P>::L, W = F29<P>::W;
     Fe29<P> t;
     fe29_carry(t, a);
-    for (int k = 19; k >= 1; k--) {
-        // if t >= k p: t -= k p   (afterwards t < p)
-        bool ge = true;
-        for (int i = F29<P>::L - 1; i >= 0; i--) {
-            if (t.v[i] != F29<P>::KP[k][i]) {
-                ge = t.v[i] > F29<P>::KP[k][i];
-                break;
-            }
+    ZK_UNROLL
+    for (int s = 4; s >= 0; s--) {
+        const int k = 1 << s;
+        uint32_t d[L];
+        int32_t br = 0;
+        ZK_UNROLL
+        for (int i = 0; i < L - 1; i++) {
+            const int32_t x = (int32_t)t.v[i] - (int32_t)F29<P>::KP[k][i] - br;
+            br = (int32_t)((uint32_t)x >> 31);
+            d[i] = (uint32_t)(x + (br << W));
         }
-        if (ge) {
-            int32_t br = 0;
-            for (int i = 0; i < F29<P>::L - 1; i++) {
-                int32_t d = (int32_t)t.v[i] - (int32_t)F29<P>::KP[k][i] - br;
-                br = d < 0;
-                t.v[i] = (uint32_t)(d + (br << F29<P>::W));
-            }
-            t.v[F29<P>::L - 1] = t.v[F29<P>::L - 1] - F29<P>::KP[k][F29<P>::L - 1] - (uint32_t)br;
-            break;
-        }
+        const int64_t top = (int64_t)t.v[L - 1] - (int64_t)F29<P>::KP[k][L - 1] - br;
+        d[L - 1] = (uint32_t)top;
+        const uint32_t keep = top < 0 ? 0u : 0xffffffffu;      // t >= k p: take the difference
+        ZK_UNROLL
+        for (int i = 0; i < L; i++) t.v[i] = (d[i] & keep) | (t.v[i] & ~keep);
     }
     r = t;
 }

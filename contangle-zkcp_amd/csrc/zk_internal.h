@@ -78,6 +78,7 @@ struct MsmTuning {
     int waves = 0;
     bool no_hot_help = false;
     bool slice_reduce = false;   // the round-1 bucket reduction (slices + multiplier) instead of row / column sums
+    bool device_partials = false;   // ZK_MSM_FLAG_DEVICE_PARTIALS: partial sums converted on the device, checked against the host's conversion
     bool precomputed = false;    // ONE bucket set over the handle's precomputed window multiples (ZK_MSM_FLAG_PRECOMPUTED)
     uint64_t base_offset = 0;
     uint32_t batch = 1;          // internal (zk_msm_batch_device): scalar vectors summed by ONE job
@@ -93,7 +94,7 @@ struct MsmJob {
     uint64_t ticket = 0;
     hipStream_t stream = nullptr;
     DevBuf scalars_in;                // staging for scalars that arrive from the host or from a peer device
-    DevBuf hot, counts, digits, blockcnt, stage_idx, stage_low, queue, seg_out, subacc, sorted, buckets, part_a, part_b;
+    DevBuf hot, counts, digits, blockcnt, stage_idx, stage_low, queue, seg_out, subacc, sorted, buckets, part_a, part_b, part_std;
     void* host_partials = nullptr;    // pinned
     size_t host_cap = 0;
     hipEvent_t ev[8];                 // [0] begin .. [5] reduced, [6] partials on the host, [7] accumulate kernel done
@@ -105,6 +106,7 @@ struct MsmJob {
     uint32_t per = 0;                 // partial sums per window
     bool axes = false;                // row / column reduction: per window [row blocks | column blocks] x (weighted, plain)
     uint32_t row_blocks = 0, col_blocks = 0, log_cols = 0, log_tl = 0;
+    bool dev_std = false;             // host_partials = [raw | converted on the device | conversion stages] (ZK_MSM_FLAG_DEVICE_PARTIALS)
     bool empty = true;                // nothing was launched (n == 0 or no windows): the result is the identity
     zk_msm_profile prof;
     double alg_bytes = 0;             // n x (scalar + affine point bytes) x share of the windows

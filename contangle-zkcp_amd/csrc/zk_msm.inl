@@ -31,9 +31,45 @@ int msm_finish_impl(MsmJob& job, void* out_jac) {
         const XYZZ<CK>* host = (const XYZZ<CK>*)job.host_partials + (size_t)bt * job.nw * job.per;
         HostXYZZ<C> htotal, hp;
         to_host<C>(htotal, total);
+        // ZK_MSM_FLAG_DEVICE_PARTIALS: the reduction's last kernel also wrote every partial in the caller's limb form (and the
+        // stages of that conversion); the result is built from those, and each is checked against the host's conversion of
+        // the raw partial -- prof.reserved = mismatching partials | first differing stage << 24 | its component << 28
+        const size_t nparts = (size_t)job.batch * job.nw * job.per;
+        const XYZZ<C>* host_std = job.dev_std ? (const XYZZ<C>*)((const XYZZ<CK>*)job.host_partials + nparts) : nullptr;
+        const uint32_t* host_dbg = job.dev_std ? (const uint32_t*)(host_std + nparts) : nullptr;
         auto load = [&](HostXYZZ<C>& r, size_t i) {
             XYZZ<C> ps;
             partial_to_std<C>(ps, host[i]);
+            if (host_std) {
+                const size_t gi = (size_t)bt * job.nw * job.per + i;
+                if (memcmp(&ps, &host_std[gi], sizeof ps) != 0) {
+                    if ((job.prof.reserved & 0xffffff) == 0) {
+                        constexpr uint32_t DW = partial_dbg_words<CK>();
+                        int stage = 5, comp = 0;
+                        if constexpr (DW != 0) {
+                            std::vector<uint32_t> mine(DW);
+                            partial_std_stages<CK>(host[i], mine.data());
+                            const uint32_t* dev = host_dbg + gi * DW;
+                            using F = typename CK::Fq;
+                            constexpr uint32_t L = F29<F>::L, N = F::N, PER = 3 * L + N;
+                            for (uint32_t k = 0; k < DW && stage == 5; k++)
+                                if (mine[k] != dev[k]) {
+                                    comp = (int)(k / PER);
+                                    const uint32_t o = k % PER;
+                                    stage = o < L ? 1 : o < 2 * L ? 2 : o < 3 * L ? 3 : 4;
+                                    fprintf(stderr, "zk: device partial %zu differs: component %d, stage %d (1 norm, 2 product, 3 canonical, 4 packed), word %u\n",
+                                            gi, comp, stage, o);
+                                    const uint32_t b0 = (uint32_t)comp * PER;
+                                    for (uint32_t q = 0; q < PER; q++)
+                                        fprintf(stderr, "   [%2u] host %08x dev %08x%s\n", q, mine[b0 + q], dev[b0 + q], mine[b0 + q] != dev[b0 + q] ? "  <--" : "");
+                                }
+                        }
+                        job.prof.reserved |= (stage << 24) | (comp << 28);
+                    }
+                    job.prof.reserved++;
+                }
+                ps = host_std[gi];
+            }
             to_host<C>(r, ps);
         };
         for (int w = job.nw - 1; w >= 0; w--) {
@@ -102,6 +138,7 @@ template <class C, class CK>
 int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
     hipStream_t st = job.stream;
     memset(&job.prof, 0, sizeof job.prof);
+    job.dev_std = false;
     job.finish = &msm_finish_impl<C, CK>;
     job.empty = true;
     const int c = msm_pick_c(n, tu.window_bits);
@@ -340,7 +377,21 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
             cur = elem + (size_t)A.nw * (A.rows + A.cols);
             ZK_LAUNCH((msm_axis_partials_kernel<CK>), (A.row_lanes + A.col_lanes + 63) / 64, 64, 0, st, (const XYZZ<CK>*)buckets, part, A);
             ZK_LAUNCH((msm_axis_fold_kernel<CK>), fr + fc, TL, 0, st, (const XYZZ<CK>*)part, elem, A, fr);
-            ZK_LAUNCH((msm_axis_weighted_kernel<CK>), A.nw * (rb + cb), TL, 0, st, (const XYZZ<CK>*)elem, cur, A, rb, cb);
+            if (tu.device_partials && ViewBase<CK>::LAZY) {
+                // [raw partials | converted partials | conversion stages], copied to the host as one block
+                const size_t np = (size_t)A.nw * per;
+                const size_t bytes = np * (sizeof(XYZZ<CK>) + sizeof(XYZZ<C>) + 4 * (size_t)partial_dbg_words<CK>());
+                ZK_TRY(ws_get(job.part_std, bytes));
+                cur = (XYZZ<CK>*)job.part_std.p;
+                XYZZ<C>* cur_std = (XYZZ<C>*)(cur + np);
+                uint32_t* dbg = (uint32_t*)(cur_std + np);
+                ZK_LAUNCH((msm_axis_weighted_kernel<CK, true>), A.nw * (rb + cb), TL, 0, st, (const XYZZ<CK>*)elem, cur, A, rb, cb,
+                          (XYZZ<typename ViewBase<CK>::type>*)cur_std, dbg);
+                job.dev_std = true;
+            } else {
+                ZK_LAUNCH((msm_axis_weighted_kernel<CK>), A.nw * (rb + cb), TL, 0, st, (const XYZZ<CK>*)elem, cur, A, rb, cb,
+                          (XYZZ<typename ViewBase<CK>::type>*)nullptr, (uint32_t*)nullptr);
+            }
             job.row_blocks = rb;
             job.col_blocks = cb;
             job.log_cols = A.log_cols;
@@ -376,7 +427,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         }
         HIP_TRY(hipEventRecord(ev[5], st));
         HIP_TRY(hipGetLastError());
-        const size_t hbytes = (size_t)nw_all * per * sizeof(XYZZ<CK>);
+        const size_t hbytes = (size_t)nw_all * per * (sizeof(XYZZ<CK>) + (job.dev_std ? sizeof(XYZZ<C>) + 4 * (size_t)partial_dbg_words<CK>() : 0));
         if (job.host_cap < hbytes) {
             if (job.host_partials) hipHostFree(job.host_partials);
             job.host_partials = nullptr;

@@ -1116,20 +1116,73 @@ __global__ void __launch_bounds__(256) msm_axis_fold_kernel(const XYZZ<C>* __res
 //   out[2 i + 1] = sum_t x_t                 (the first suffix sum)
 // the partial sums go to the host in the kernel view's limb form: the host converts (partial_to_std) while it adds them up
 template <class CB>
-inline void partial_to_std(XYZZ<CB>& r, const XYZZ<CB>& p) {
+ZK_HD void partial_to_std(XYZZ<CB>& r, const XYZZ<CB>& p) {
     r = p;
 }
 template <class CB>
-inline void partial_to_std(XYZZ<CB>& r, const XYZZ<C29<CB>>& p) {
+ZK_HD void partial_to_std(XYZZ<CB>& r, const XYZZ<C29<CB>>& p) {
     xyzz29_to_std<CB>(r, p);
 }
 template <class CB>
-inline void partial_to_std(XYZZ<CB>& r, const XYZZ<C29x2<CB>>& p) {
+ZK_HD void partial_to_std(XYZZ<CB>& r, const XYZZ<C29x2<CB>>& p) {
     xyzz29_to_std<CB>(r, p);
 }
+// the curve a kernel view computes for (its caller-side limb form)
+template <class CK>
+struct ViewBase {
+    using type = CK;
+    static constexpr bool LAZY = false;
+};
 template <class C>
+struct ViewBase<C29<C>> {
+    using type = C;
+    static constexpr bool LAZY = true;
+};
+template <class C>
+struct ViewBase<C29x2<C>> {
+    using type = C;
+    static constexpr bool LAZY = true;
+};
+// ZK_MSM_FLAG_DEVICE_PARTIALS (diagnostic form): the stages of fe29_to_std of every base-field component of a lazy point, written
+// out one by one -- norm | product by FROM29 | canonical | packed words -- so that the host can name the first stage whose device
+// result differs from its own (a GPU-only wrong conversion on the BN254 curves)
+template <class CK>
+constexpr uint32_t partial_dbg_words() {
+    if constexpr (ViewBase<CK>::LAZY) {
+        using F = typename CK::Fq;
+        return (uint32_t)(sizeof(XYZZ<CK>) / sizeof(Fe29<F>)) * (3u * F29<F>::L + (uint32_t)F::N);
+    } else {
+        return 0;
+    }
+}
+template <class CK>
+ZK_HD void partial_std_stages(const XYZZ<CK>& p, uint32_t* dbg) {
+    if constexpr (ViewBase<CK>::LAZY) {
+        using F = typename CK::Fq;
+        constexpr int L = F29<F>::L, N = F::N;
+        constexpr int NC = (int)(sizeof(XYZZ<CK>) / sizeof(Fe29<F>));
+        const Fe29<F>* comp = reinterpret_cast<const Fe29<F>*>(&p);
+        for (int j = 0; j < NC; j++) {
+            Fe29<F> t, c;
+            Fe<F> w;
+            for (int i = 0; i < L; i++) c.v[i] = F29<F>::FROM29[i];
+            fe29_norm(t, comp[j]);
+            for (int i = 0; i < L; i++) dbg[i] = t.v[i];
+            fe29_mul(t, t, c);
+            for (int i = 0; i < L; i++) dbg[L + i] = t.v[i];
+            fe29_canon(t, t);
+            for (int i = 0; i < L; i++) dbg[2 * L + i] = t.v[i];
+            fe29_pack(w, t);
+            for (int i = 0; i < N; i++) dbg[3 * L + i] = w.v[i];
+            dbg += 3 * L + N;
+        }
+    }
+}
+template <class C, bool STD = false>
 __global__ void __launch_bounds__(256) msm_axis_weighted_kernel(const XYZZ<C>* __restrict__ elem, XYZZ<C>* __restrict__ out, MsmAxes A,
-                                                                uint32_t row_blocks, uint32_t col_blocks) {
+                                                                uint32_t row_blocks, uint32_t col_blocks,
+                                                                XYZZ<typename ViewBase<C>::type>* __restrict__ out_std = nullptr,
+                                                                uint32_t* __restrict__ dbg = nullptr) {
     constexpr uint32_t TL = tree_lanes<C>();
     __shared__ XYZZ<C> sh[TL];
     const uint32_t tid = threadIdx.x;
@@ -1173,6 +1226,17 @@ __global__ void __launch_bounds__(256) msm_axis_weighted_kernel(const XYZZ<C>* _
     if (tid == 0) {
         out[2 * (uint64_t)blockIdx.x] = acc;
         out[2 * (uint64_t)blockIdx.x + 1] = total;
+        if constexpr (STD) {
+            XYZZ<typename ViewBase<C>::type> s0, s1;
+            partial_to_std<typename ViewBase<C>::type>(s0, acc);
+            partial_to_std<typename ViewBase<C>::type>(s1, total);
+            out_std[2 * (uint64_t)blockIdx.x] = s0;
+            out_std[2 * (uint64_t)blockIdx.x + 1] = s1;
+            if (dbg) {
+                partial_std_stages<C>(acc, dbg + (2 * (uint64_t)blockIdx.x) * partial_dbg_words<C>());
+                partial_std_stages<C>(total, dbg + (2 * (uint64_t)blockIdx.x + 1) * partial_dbg_words<C>());
+            }
+        }
     }
 }
 

@@ -158,7 +158,9 @@ int pow_tables(DeviceCtx& dc, const Fe<F>& gshift, uint32_t logn, int field, hip
 // size-2^logn DFT of `a` with root omega; optionally fused with a[i] *= g_pre^i before and a[k] *= g_post^k after
 template <class F>
 int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st, const Fe<F>* g_pre,
-            const Fe<F>* g_post, uint32_t in_log) {
+            const Fe<F>* g_post, uint32_t in_log, const Fe<F>* src0) {
+    // src0 (optional): the input is read from there by the first pass and left untouched; the result lands in `a` (out of place)
+    if (!src0) src0 = a;
     if (logn > (uint32_t)F::TWO_ADICITY || logn > 30) return ZK_ERR_INVALID_ARG;   // before anything is sized from logn
     if (logn == 0) return ZK_OK;  // size-1 transform is the identity, n^-1 = 1 and g^0 = 1
     // lazy 29-bit limbs inside the tiles (zk_ntt29_kernels.h) unless zk_ntt_opts asks for the saturated words
@@ -207,10 +209,10 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
         const Fe<F>* src;
         Fe<F>* dst;
         if (plan.nd == 1) {
-            src = a;
+            src = src0;
             dst = a;
         } else if (p == 0) {
-            src = a;
+            src = src0;
             dst = tmp;
         } else if (A.last) {
             src = tmp;

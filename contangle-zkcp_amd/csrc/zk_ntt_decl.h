@@ -14,7 +14,7 @@ struct R1csMatrix {
 };
 template <class F>
 int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omega, int scale_flag, hipStream_t st,
-            const Fe<F>* g_pre = nullptr, const Fe<F>* g_post = nullptr, uint32_t in_log = 0);
+            const Fe<F>* g_pre = nullptr, const Fe<F>* g_post = nullptr, uint32_t in_log = 0, const Fe<F>* src0 = nullptr);
 template <class F>
 int coset_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& gshift, hipStream_t st);
 template <class F>
@@ -36,9 +36,13 @@ int lookup_product_run(DeviceCtx& dc, const Fe<F>* A, const Fe<F>* S, const Fe<F
 template <class F>
 int inner_product_run(DeviceCtx& dc, const Fe<F>* a, const Fe<F>* b, uint64_t n, void* out_host, hipStream_t st);
 template <class F>
-int vec_muladd_run(Fe<F>* a, const Fe<F>* b, uint64_t n, const Fe<F>& s, hipStream_t st);
+int vec_muladd_run(Fe<F>* out, const Fe<F>* a, const Fe<F>* b, uint64_t n, const Fe<F>& s, hipStream_t st);
 template <class F>
 int poly_eval_run(DeviceCtx& dc, const Fe<F>* c, uint64_t n, uint32_t count, uint64_t stride, const Fe<F>& x, int field, void* out_host, hipStream_t st);
+template <class F>
+int vec_powers_run(DeviceCtx& dc, Fe<F>* out, uint64_t n, const Fe<F>& x, hipStream_t st);
+template <class F>
+int kate_division_run(DeviceCtx& dc, const Fe<F>* a, Fe<F>* q, uint64_t n, const Fe<F>& x, hipStream_t st);
 template <class F>
 int vec_fold_run(Fe<F>* a, uint64_t half, const Fe<F>& c, hipStream_t st);
 template <class F>

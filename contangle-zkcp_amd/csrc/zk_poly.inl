@@ -168,6 +168,70 @@ int ipa_round_end_run(DeviceCtx& dc, hipStream_t st, void* vl_host, void* vr_hos
     return ZK_OK;
 }
 
+// the power tables of x (x^j for j < 1024 and x^(1024 j), j < 2^(logn - 10)) built in the stream's scratch (poly_b) for one call: an
+// evaluation / division point is a fresh transcript challenge, caching it beside the NTT twiddle tables would only evict those
+template <class F>
+int scratch_pow_tables(StreamScratch& ss, const Fe<F>& x, uint32_t logn, hipStream_t st, PowTables<F>* out) {
+    if (logn < 1) logn = 1;
+    const uint64_t nlo = logn >= 10 ? 1024 : (1ull << logn), nhi = logn > 10 ? (1ull << (logn - 10)) : 1;
+    ZK_TRY(ws_get(ss.poly_b, sizeof(Fe<F>) * (nlo + nhi + 64)));
+    Fe<F>* tbl = (Fe<F>*)ss.poly_b.p;
+    Fe<F>* d_lad = tbl + nlo + nhi;
+    ZK_LAUNCH((pow_ladder_kernel<F>), 1, 64, 0, st, x, d_lad);   // x^(2^k) and (x^1024)^(2^k), on the device: no host staging, no stall
+    ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nlo + 255) / 256), 256, 0, st, tbl, (const Fe<F>*)d_lad, nlo, 10);
+    ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nhi + 255) / 256), 256, 0, st, tbl + nlo, (const Fe<F>*)(d_lad + 32), nhi, 22);
+    HIP_TRY(hipGetLastError());
+    out->lo = tbl;
+    out->hi = tbl + nlo;
+    return ZK_OK;
+}
+
+template <class F>
+int vec_powers_run(DeviceCtx& dc, Fe<F>* out, uint64_t n, const Fe<F>& x, hipStream_t st) {
+    if (n == 0) return ZK_OK;
+    if (n > (1ull << 30)) return ZK_ERR_UNSUPPORTED;
+    uint32_t logn = 0;
+    while ((1ull << logn) < n) logn++;
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    PowTables<F> pw;
+    ZK_TRY(scratch_pow_tables<F>(*ss, x, logn, st, &pw));
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ZK_LAUNCH((vec_powers_kernel<F>), (unsigned)blocks, 256, 0, st, out, n, pw);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+// q = (a - a(x)) / (X - x), n coefficients in, n out (q[n - 1] = 0); a == q allowed  (zk_poly_kernels.h, kate_*)
+template <class F>
+int kate_division_run(DeviceCtx& dc, const Fe<F>* a, Fe<F>* q, uint64_t n, const Fe<F>& x, hipStream_t st) {
+    if (n == 0) return ZK_OK;
+    if (n > (1ull << 30)) return ZK_ERR_UNSUPPORTED;
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    const uint64_t per_wg = (uint64_t)KATE_WG * KATE_K;
+    const uint32_t nblocks = (uint32_t)((n + per_wg - 1) / per_wg);
+    ZK_TRY(ws_get(ss->poly_tot, (size_t)nblocks * sizeof(Fe<F>)));
+    Fe<F>* tot = (Fe<F>*)ss->poly_tot.p;
+    KatePows<F> kp;
+    Fe<F> w = x;
+    for (uint32_t k = 1; k < KATE_K; k <<= 1) fe_sqr(w, w);        // x^16
+    for (uint32_t s = 0; s <= KATE_LOG_WG; s++) {
+        kp.xk[s] = w;
+        fe_sqr(w, w);
+    }
+    ZK_LAUNCH((kate_block_kernel<F>), nblocks, KATE_WG, 0, st, a, q, tot, n, x, kp);
+    if (nblocks > 1) {
+        PowTables<F> pw;
+        ZK_TRY(scratch_pow_tables<F>(*ss, x, 12, st, &pw));        // exponents below 4096
+        ZK_LAUNCH((kate_totals_kernel<F>), 1, KATE_WG, 0, st, tot, nblocks, kp.xk[KATE_LOG_WG]);
+        ZK_LAUNCH((kate_apply_kernel<F>), nblocks, KATE_WG, 0, st, q, (const Fe<F>*)tot, n, x, pw);
+    }
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
 // p_q(x) for `count` resident coefficient vectors of n elements (stride apart), all at the same x (Montgomery form): one
 // launch, one copy.  Synchronises the stream (the results are host values).
 template <class F>
@@ -182,32 +246,9 @@ int poly_eval_run(DeviceCtx& dc, const Fe<F>* c, uint64_t n, uint32_t count, uin
         while ((1ull << logn) < n) logn++;
         StreamScratch* ss = nullptr;
         ZK_TRY(stream_scratch(dc, st, &ss));
-        // the power tables of x (g^j for j < 1024 and g^(1024 j)) are built in the stream's scratch for this call: an evaluation
-        // point is a fresh transcript challenge, caching it beside the NTT twiddle tables would only evict those
         (void)field;
-        if (logn < 1) logn = 1;
-        const uint64_t nlo = logn >= 10 ? 1024 : (1ull << logn), nhi = logn > 10 ? (1ull << (logn - 10)) : 1;
-        ZK_TRY(ws_get(ss->poly_b, sizeof(Fe<F>) * (nlo + nhi + 64)));
-        Fe<F>* tbl = (Fe<F>*)ss->poly_b.p;
-        Fe<F>* d_lad = tbl + nlo + nhi;
-        std::vector<Fe<F>> lad(64);
-        {
-            Fe<F> w = x;
-            for (int k = 0; k < 10; k++) {
-                lad[k] = w;
-                fe_sqr(w, w);
-            }
-            for (int k = 0; k < 22; k++) {   // w = x^1024 here
-                lad[32 + k] = w;
-                fe_sqr(w, w);
-            }
-        }
-        HIP_TRY(hipMemcpyAsync(d_lad, lad.data(), sizeof(Fe<F>) * 64, hipMemcpyHostToDevice, st));
-        ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nlo + 255) / 256), 256, 0, st, tbl, (const Fe<F>*)d_lad, nlo, 10);
-        ZK_LAUNCH((pow_table_kernel<F>), (unsigned)((nhi + 255) / 256), 256, 0, st, tbl + nlo, (const Fe<F>*)(d_lad + 32), nhi, 22);
         PowTables<F> pw;
-        pw.lo = tbl;
-        pw.hi = tbl + nlo;
+        ZK_TRY(scratch_pow_tables<F>(*ss, x, logn, st, &pw));
         uint64_t blocks = ((n + EVAL_K - 1) / EVAL_K + 255) / 256;
         if (blocks > 256) blocks = 256;
         ZK_TRY(ws_get(ss->poly_tot, blocks * count * sizeof(Fe<F>)));
@@ -230,11 +271,11 @@ int poly_eval_run(DeviceCtx& dc, const Fe<F>* c, uint64_t n, uint32_t count, uin
 }
 
 template <class F>
-int vec_muladd_run(Fe<F>* a, const Fe<F>* b, uint64_t n, const Fe<F>& s, hipStream_t st) {
+int vec_muladd_run(Fe<F>* out, const Fe<F>* a, const Fe<F>* b, uint64_t n, const Fe<F>& s, hipStream_t st) {
     if (n == 0) return ZK_OK;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    ZK_LAUNCH((vec_muladd_kernel<F>), (unsigned)blocks, 256, 0, st, a, b, n, s);
+    ZK_LAUNCH((vec_muladd_kernel<F>), (unsigned)blocks, 256, 0, st, out, a, b, n, s);
     HIP_TRY(hipGetLastError());
     return ZK_OK;
 }

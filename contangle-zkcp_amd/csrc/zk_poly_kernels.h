@@ -7,6 +7,7 @@
 //   inner_product_kernel           compute_inner_product (the value_l / value_r of an IPA round)
 //   vec_fold_kernel                a[i] += c a[i + half]  (the p' and b folds of an IPA round)
 //   poly_eval_kernel               eval_polynomial: p(x) for a resident coefficient vector
+//   kate_block / kate_totals / kate_apply   kate_division: (a - a(x)) / (X - x), the multiopen argument's per-point division
 //   expr_eval_kernel               the quotient numerator: a stack program over extended-domain columns with rotations
 // All HBM-streaming with a handful of Montgomery products per element; the scans are three launches (block products,
 // scan of the block totals by one workgroup, apply).
@@ -224,13 +225,41 @@ __global__ void __launch_bounds__(256) inner_product_kernel(const Fe<F>* __restr
 // a[i] = a[i] * s + b[i]: one Horner step of the multiopen combination (poly/multiopen/prover.rs: the polynomials queried at the
 // same point set are folded with powers of x_1, the per-set quotients with x_4) on resident coefficient vectors
 template <class F>
-__global__ void __launch_bounds__(256) vec_muladd_kernel(Fe<F>* __restrict__ a, const Fe<F>* __restrict__ b, uint64_t n, Fe<F> s) {
+__global__ void __launch_bounds__(256) vec_muladd_kernel(Fe<F>* out, const Fe<F>* a, const Fe<F>* __restrict__ b, uint64_t n, Fe<F> s) {
+    // out[i] = a[i] s + b[i]; out == a is the in-place Horner step (every lane reads its element before it writes it)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         Fe<F> x = a[i];
         const Fe<F> y = b[i];
         fe_mul(x, x, s);
         fe_add(x, x, y);
-        a[i] = x;
+        out[i] = x;
+    }
+}
+
+// lad[k] = x^(2^k), k < 10 ; lad[32 + k] = (x^1024)^(2^k), k < 22: the ladders pow_table_kernel builds the power tables of a fresh
+// challenge from (one lane: 32 dependent squarings)
+template <class F>
+__global__ void __launch_bounds__(64) pow_ladder_kernel(Fe<F> x, Fe<F>* __restrict__ lad) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fe<F> w = x;
+    for (int k = 0; k < 10; k++) {
+        lad[k] = w;
+        fe_sqr(w, w);
+    }
+    for (int k = 0; k < 22; k++) {
+        lad[32 + k] = w;
+        fe_sqr(w, w);
+    }
+}
+
+// out[i] = x^i (poly/commitment/prover.rs builds `b`, the powers of x_3, this way before the argument's rounds)
+template <class F>
+__global__ void __launch_bounds__(256) vec_powers_kernel(Fe<F>* __restrict__ out, uint64_t n, PowTables<F> pw) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<F> a = pw.lo[i & 1023];
+        const Fe<F> b = pw.hi[i >> 10];
+        fe_mul(a, a, b);
+        out[i] = a;
     }
 }
 
@@ -270,6 +299,128 @@ __global__ void __launch_bounds__(256) poly_eval_kernel(const Fe<F>* __restrict_
         __syncthreads();
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// ---- kate_division (halo2_proofs 0.2 arithmetic.rs; poly/multiopen/prover.rs divides every point set's folded polynomial by
+// (X - x) for each of its points): q = (a - a(x)) / (X - x), i.e. q[j] = sum_{i > j} a[i] x^(i - j - 1) and q[n - 1] = 0 (upstream
+// returns n - 1 coefficients and the multiopen prover resizes to n).  With A(j) = sum_{i >= j} a[i] x^(i - j) the output is
+// q[j] = A(j + 1): a suffix Horner recurrence, run as a three-phase scan like the grand products --
+//   kate_block_kernel    workgroup = 4096 coefficients: per-lane Horner of 16, LDS suffix scan over the lanes with the weights
+//                        x^16, x^32, ..., then q inside the block (as if nothing followed it) and the block's total A_block
+//   kate_totals_kernel   one workgroup: block_tot[b] <- C_b = A(end of block b) from the totals, weight x^4096
+//   kate_apply_kernel    q[j] += x^(end_b - j - 1) C_b
+// ~3 products per coefficient; a == q allowed (every lane reads its 16 coefficients before it writes them).
+constexpr uint32_t KATE_K = 16, KATE_WG = 256, KATE_LOG_WG = 8;
+template <class F>
+struct KatePows {
+    Fe<F> xk[KATE_LOG_WG + 1];   // x^(KATE_K 2^s), s = 0 .. 8: the lane weights of the scan; xk[8] = x^4096 is the block weight
+};
+template <class F>
+__global__ void __launch_bounds__(KATE_WG) kate_block_kernel(const Fe<F>* a, Fe<F>* q, Fe<F>* __restrict__ block_tot, uint64_t n, Fe<F> x,
+                                                             KatePows<F> pw) {
+    __shared__ Fe<F> part[KATE_WG];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t lo = ((uint64_t)blockIdx.x * KATE_WG + tid) * KATE_K;
+    Fe<F> v[KATE_K], h;
+    fe_zero(h);
+    for (int k = (int)KATE_K - 1; k >= 0; k--) {
+        if (lo + k < n)
+            v[k] = a[lo + k];
+        else
+            fe_zero(v[k]);
+        fe_mul(h, h, x);
+        fe_add(h, h, v[k]);
+    }
+    part[tid] = h;
+    __syncthreads();
+    Fe<F> acc = h;
+    for (uint32_t s = 0; s < KATE_LOG_WG; s++) {      // inclusive suffix scan: acc_t = sum_{t' >= t} h_t' x^(16 (t' - t))
+        const uint32_t d = 1u << s;
+        const bool on = tid + d < KATE_WG;
+        Fe<F> o;
+        if (on) o = part[tid + d];
+        __syncthreads();
+        if (on) {
+            fe_mul(o, o, pw.xk[s]);
+            fe_add(acc, acc, o);
+            part[tid] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) block_tot[blockIdx.x] = acc;
+    Fe<F> r;
+    if (tid + 1 < KATE_WG)
+        r = part[tid + 1];
+    else
+        fe_zero(r);
+    for (int k = (int)KATE_K - 1; k >= 0; k--) {
+        if (lo + k < n) q[lo + k] = r;
+        fe_mul(r, r, x);
+        fe_add(r, r, v[k]);
+    }
+}
+// one workgroup: block_tot[b] <- sum_{b' > b} T_b' X^(b' - b - 1), X = x^4096
+template <class F>
+__global__ void __launch_bounds__(KATE_WG) kate_totals_kernel(Fe<F>* __restrict__ block_tot, uint32_t nblocks, Fe<F> X) {
+    __shared__ Fe<F> part[KATE_WG];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (nblocks + KATE_WG - 1) / KATE_WG;
+    const uint32_t lo = tid * per < nblocks ? tid * per : nblocks, hi = lo + per < nblocks ? lo + per : nblocks;
+    Fe<F> h;
+    fe_zero(h);
+    for (uint32_t j = hi; j-- > lo;) {
+        const Fe<F> t = block_tot[j];
+        fe_mul(h, h, X);
+        fe_add(h, h, t);
+    }
+    Fe<F> m;                   // X^per: the weight between neighbouring lanes (every lane spans `per` blocks, missing ones count as zero)
+    fe_one(m);
+    for (uint32_t k = 0; k < per; k++) fe_mul(m, m, X);
+    part[tid] = h;
+    __syncthreads();
+    Fe<F> acc = h;
+    for (uint32_t d = 1; d < KATE_WG; d <<= 1) {
+        const bool on = tid + d < KATE_WG;
+        Fe<F> o;
+        if (on) o = part[tid + d];
+        __syncthreads();
+        if (on) {
+            fe_mul(o, o, m);
+            fe_add(acc, acc, o);
+            part[tid] = acc;
+        }
+        __syncthreads();
+        fe_sqr(m, m);
+    }
+    Fe<F> r;
+    if (tid + 1 < KATE_WG)
+        r = part[tid + 1];
+    else
+        fe_zero(r);
+    for (uint32_t j = hi; j-- > lo;) {
+        const Fe<F> t = block_tot[j];
+        block_tot[j] = r;
+        fe_mul(r, r, X);
+        fe_add(r, r, t);
+    }
+}
+template <class F>
+__global__ void __launch_bounds__(KATE_WG) kate_apply_kernel(Fe<F>* __restrict__ q, const Fe<F>* __restrict__ carry, uint64_t n, Fe<F> x,
+                                                             PowTables<F> pw) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t lo = ((uint64_t)blockIdx.x * KATE_WG + tid) * KATE_K;
+    if (lo >= n) return;
+    Fe<F> m = carry[blockIdx.x];
+    if (fe_is_zero(m)) return;                                   // (the last block; wave-uniform)
+    mul_pow(m, pw, (uint64_t)(KATE_WG - 1 - tid) * KATE_K);      // C_b x^(end_b - lo - 16)
+    for (int k = (int)KATE_K - 1; k >= 0; k--) {
+        if (lo + k < n) {
+            Fe<F> y = q[lo + k];
+            fe_add(y, y, m);
+            q[lo + k] = y;
+        }
+        fe_mul(m, m, x);
+    }
 }
 
 template <class F>

@@ -63,6 +63,45 @@ def _gather_add(curves, parts, group):
     return res
 
 
+_gather_tmp = {}
+
+
+def gather_parts(local, out, stream=None, group=None):
+    """The sharded quotient's one exchange: rank j holds h on its sub-coset (local[i] = the extended evaluation i * world + j);
+    afterwards every rank holds the whole extended vector, out[i * world + j] = rank j's local[i].  ONE all_gather of
+    32 bytes per extended row over RCCL (device to device), then a strided copy; `local` and `out` are device buffers
+    (numpy arrays under the CPU test emulator)."""
+    world, rank = _world(group)
+    m = int(local.shape[0])
+    if world == 1:
+        if out is not local:
+            out[:] = local
+        return out
+    assert int(out.shape[0]) == m * world
+    if isinstance(local, np.ndarray):                                  # CPU tests: "device" memory is host memory
+        t = torch.from_numpy(np.ascontiguousarray(local).view(np.int64))
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t, group=group)
+        stacked = np.stack([o.numpy().view(np.uint64).reshape(m, -1) for o in outs])
+        out[:] = stacked.transpose(1, 0, 2).reshape(m * world, -1)
+        return out
+    width = int(local.shape[1])
+    if dist.get_backend(group) == "nccl":
+        key = (world, m, width, local.device)
+        if key not in _gather_tmp:
+            _gather_tmp.clear()
+            _gather_tmp[key] = torch.empty((world, m, width), dtype=local.dtype, device=local.device)
+        tmp = _gather_tmp[key]
+        dist.all_gather_into_tensor(tmp.view(-1), local.reshape(-1), group=group)     # ordered with the current stream on both sides
+    else:                                                              # gloo rehearsal on a GPU box: staged through the host
+        t = local.cpu()
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t, group=group)
+        tmp = torch.stack(outs).to(local.device)
+    out.view(m, world, width).copy_(tmp.permute(1, 0, 2))
+    return out
+
+
 def msm_sharded(bases, scalars, montgomery=False, window_bits=0, group=None, stream=0):
     """All ranks call with the same bases/scalars; returns the full Jacobian sum on every rank."""
     world, rank = _world(group)

@@ -20,7 +20,7 @@ from . import (Bases, _check, _np64, _ptr, base_limbs, curve_id, field_id, field
 PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo2_permutation_product_device",
                   "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
                   "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device", "zk_ipa_collapse_range_device", "zk_ipa_round_device",
-                  "zk_poly_eval_device", "zk_poly_eval_batch_device", "zk_vec_muladd_device"]
+                  "zk_poly_eval_device", "zk_poly_eval_batch_device", "zk_vec_muladd_device", "zk_vec_muladd_to_device", "zk_kate_division_device", "zk_vec_powers_device"]
 
 
 def best_multiexp(coeffs, bases):
@@ -96,10 +96,15 @@ class EvaluationDomain:
         return 1 << self.extended_k
 
     # ---- device buffers (torch tensors; numpy under the CPU test emulator), in place
-    def lagrange_to_coeff(self, a, stream=0):
-        """ifft(a, omega_inv, k, ifft_divisor): best_fft with omega^-1, then every element times n^-1"""
+    def lagrange_to_coeff(self, a, stream=0, out=None):
+        """ifft(a, omega_inv, k, ifft_divisor): best_fft with omega^-1, then every element times n^-1.  out: write the
+        coefficients there and leave the Lagrange values alone (upstream returns a new Polynomial; the prover keeps both)"""
         if int(a.shape[0]) != self.n:
             raise AssertionError("assertion failed: a.values.len() == 1 << self.k")
+        if out is not None:
+            if int(out.shape[0]) != self.n:
+                raise AssertionError("assertion failed: out.len() == 1 << self.k")
+            return ntt(self.field, out, self.omega_inv, scale_by_n_inv=True, stream=stream, src=a)
         return ntt(self.field, a, self.omega_inv, scale_by_n_inv=True, stream=stream, device=True)
 
     def coeff_to_lagrange(self, a, stream=0):
@@ -107,11 +112,16 @@ class EvaluationDomain:
             raise AssertionError("assertion failed: a.values.len() == 1 << self.k")
         return ntt(self.field, a, self.omega, stream=stream, device=True)
 
-    def coeff_to_extended(self, a_ext, stream=0):
+    def coeff_to_extended(self, a_ext, stream=0, coeffs=None):
         """`a_ext`: buffer of extended_len() whose first n entries are the coefficients (the rest is treated as the zeros
-        upstream's `resize` appends): distribute_powers_zeta(into_coset) ; best_fft(extended_omega)"""
+        upstream's `resize` appends): distribute_powers_zeta(into_coset) ; best_fft(extended_omega).  coeffs: take the n
+        coefficients from that buffer instead (it is left untouched: the openings evaluate it later)"""
         if int(a_ext.shape[0]) != self.extended_len():
             raise AssertionError("assertion failed: a.len() == extended_len")
+        if coeffs is not None:
+            if int(coeffs.shape[0]) != self.n:
+                raise AssertionError("assertion failed: a.len() == 1 << self.k")
+            return ntt(self.field, a_ext, self.extended_omega, stream=stream, coset_pre=self.g_coset, in_log=self.k, src=coeffs)
         return ntt(self.field, a_ext, self.extended_omega, stream=stream, coset_pre=self.g_coset,
                    in_log=self.k if self.extended_k > self.k else None, device=True)
 
@@ -121,6 +131,49 @@ class EvaluationDomain:
         if int(a_ext.shape[0]) != self.extended_len():
             raise AssertionError("assertion failed: a.values.len() == extended_len")
         return ntt(self.field, a_ext, self.extended_omega_inv, scale_by_n_inv=True, stream=stream, coset_post=self.g_coset_inv, device=True)
+
+    # ---- the extended coset in `parts` sub-cosets (one per GPU of a sharded prover): sub-coset j holds the extended
+    # evaluations e = i * parts + j, i.e. the points ZETA extended_omega^j (extended_omega^parts)^i.  Every column's values on
+    # sub-coset j are ONE transform of size extended_len / parts (coset generator ZETA extended_omega^j), rotations by r
+    # rows stay inside the sub-coset (shift r * rot_scale_part), and the vanishing polynomial takes 2^(extended_k - k) / parts
+    # values there -- so the quotient numerator shards with no exchange until h itself (32 bytes per extended row).
+    def _part_check(self, part, parts):
+        m = 1 << (self.extended_k - self.k)
+        if parts < 1 or parts > m or (parts & (parts - 1)) or not 0 <= part < parts:
+            raise AssertionError("parts must be a power of two <= 2^(extended_k - k) and 0 <= part < parts")
+
+    def part_len(self, parts):
+        return self.extended_len() // parts
+
+    def rot_scale_part(self, parts):
+        return (1 << (self.extended_k - self.k)) // parts
+
+    def _part_constants(self, part, parts):
+        key = (part, parts)
+        if not hasattr(self, "_parts"):
+            self._parts = {}
+        if key not in self._parts:
+            p = self._p
+            to_int = lambda a: sum(int(w) << (64 * i) for i, w in enumerate(a.tolist())) * pow(1 << 256, -1, p) % p
+            wi, zi = to_int(self.extended_omega), to_int(self.g_coset)
+            g = zi * pow(wi, part, p) % p
+            self._parts[key] = (_mont_limbs(g, p), _mont_limbs(pow(wi, parts, p), p))
+        return self._parts[key]
+
+    def coeff_to_extended_part(self, coeffs, out, part, parts, stream=0):
+        """out[i] = the polynomial `coeffs` (n coefficients, untouched) at ZETA extended_omega^(i parts + part), i < extended_len / parts"""
+        self._part_check(part, parts)
+        if int(coeffs.shape[0]) != self.n or int(out.shape[0]) != self.part_len(parts):
+            raise AssertionError("assertion failed: coeffs.len() == n && out.len() == extended_len / parts")
+        g, w = self._part_constants(part, parts)
+        return ntt(self.field, out, w, stream=stream, coset_pre=g, in_log=self.k, src=coeffs)
+
+    def divide_by_vanishing_poly_part(self, a_part, part, parts, stream=0):
+        """a[i] *= t_evaluations[(i parts + part) mod 2^(extended_k - k)]"""
+        self._part_check(part, parts)
+        m = 1 << (self.extended_k - self.k)
+        tbl = np.stack([self.t_evaluations[(i * parts + part) % m] for i in range(m // parts)])
+        return vec_op(self.field, "scale_periodic", a_part, b=tbl, stream=stream)
 
     def quotient_len(self):
         return self.n * self.quotient_poly_degree
@@ -158,7 +211,10 @@ def _plib():
     lib.zk_ipa_round_device.argtypes = [i32, u64, vp, vp, vp, u64, u64, vp, vp, vp, vp]
     lib.zk_poly_eval_device.argtypes = [i32, vp, u64, vp, vp, vp]
     lib.zk_vec_muladd_device.argtypes = [i32, vp, vp, u64, vp, vp]
+    lib.zk_vec_muladd_to_device.argtypes = [i32, vp, vp, vp, u64, vp, vp]
     lib.zk_poly_eval_batch_device.argtypes = [i32, vp, u64, ctypes.c_uint32, u64, vp, vp, vp]
+    lib.zk_kate_division_device.argtypes = [i32, vp, vp, u64, vp, vp]
+    lib.zk_vec_powers_device.argtypes = [i32, vp, u64, vp, vp]
     lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     return lib
 
@@ -211,9 +267,14 @@ def inner_product(field, a, b, stream=0):
     return out
 
 
-def vec_muladd(field, a, b, s, stream=0):
-    """a[i] = a[i] * s + b[i] (multiopen: folding the polynomials of a point set with powers of x_1)"""
+def vec_muladd(field, a, b, s, stream=0, out=None):
+    """a[i] = a[i] * s + b[i] (multiopen: folding the polynomials of a point set with powers of x_1); out: write there instead
+    and leave a alone (upstream clones the first polynomial of a fold)"""
     ss = _np64(s)
+    if out is not None:
+        _check(_plib().zk_vec_muladd_to_device(field_id(field), _ptr(out), _ptr(a), _ptr(b), int(a.shape[0]), _ptr(ss), ctypes.c_void_p(stream)),
+               "zk_vec_muladd_to_device")
+        return out
     _check(_plib().zk_vec_muladd_device(field_id(field), _ptr(a), _ptr(b), int(a.shape[0]), _ptr(ss), ctypes.c_void_p(stream)), "zk_vec_muladd_device")
     return a
 
@@ -234,6 +295,23 @@ def eval_polynomials(field, d_polys, x, stream=0):
     out = np.zeros((count, 4), dtype=np.uint64)
     _check(_plib().zk_poly_eval_batch_device(field_id(field), _ptr(d_polys), n, count, n, _ptr(xx), _ptr(out), ctypes.c_void_p(stream)),
            "zk_poly_eval_batch_device")
+    return out
+
+
+def vec_powers(field, out, x, stream=0):
+    """out[i] = x^i (the vector b of the inner-product argument: powers of x_3)"""
+    xx = _np64(x)
+    _check(_plib().zk_vec_powers_device(field_id(field), _ptr(out), int(out.shape[0]), _ptr(xx), ctypes.c_void_p(stream)), "zk_vec_powers_device")
+    return out
+
+
+def kate_division(field, a, x, out=None, stream=0):
+    """arithmetic.rs kate_division: (a(X) - a(x)) / (X - x) as len(a) coefficients (the last one zero: upstream returns one fewer
+    and the multiopen prover resizes); in place unless `out` is given"""
+    xx = _np64(x)
+    out = a if out is None else out
+    _check(_plib().zk_kate_division_device(field_id(field), _ptr(a), _ptr(out), int(a.shape[0]), _ptr(xx), ctypes.c_void_p(stream)),
+           "zk_kate_division_device")
     return out
 
 
@@ -317,8 +395,10 @@ class IpaProverVirtual:
     surviving points as multi-scalar multiplications that share their scalars) and continues over them: the first rounds
     cost one full-size MSM each, the remaining ones only what their own size costs."""
 
-    def __init__(self, curve, d_p, d_b, bases, new_buffer, stream=0):
-        """new_buffer(shape) -> zero device buffer (torch on the GPU, numpy under the test emulator)"""
+    def __init__(self, curve, d_p, d_b, bases, new_buffer, stream=0, buffers=None):
+        """new_buffer(shape) -> zero device buffer (torch on the GPU, numpy under the test emulator).
+        buffers = (S [2, n, 4], W [n, 4]): caller-owned scratch reused across proofs (no allocation inside the argument);
+        every entry is rewritten on the stream before it is read"""
         self.curve, self.field = curve_id(curve), scalar_field(curve)
         self.p, self.b, self.bases, self.stream = d_p, d_b, bases, stream
         self.new_buffer = new_buffer
@@ -326,12 +406,20 @@ class IpaProverVirtual:
         assert self.n & (self.n - 1) == 0 and int(d_b.shape[0]) == self.n and bases.n >= self.n
         self._own_bases = None
         self._g = None
+        self._buffers = buffers
+        if buffers is not None:
+            assert int(buffers[0].shape[0]) == 2 and int(buffers[0].shape[1]) >= self.n and int(buffers[1].shape[0]) >= self.n
         self._fresh_weights()
 
     def _fresh_weights(self):
+        one = _mont_limbs(1, field_modulus(self.field))
+        if self._buffers is not None:       # prefixes of the caller's buffers; W = 1 everywhere as the powers of 1, on the stream
+            self.S = self._buffers[0].reshape(-1)[: 2 * self.m0 * 4].reshape(2, self.m0, 4)
+            self.W = self._buffers[1][: self.m0]
+            vec_powers(self.field, self.W, one, stream=self.stream)
+            return
         self.S = self.new_buffer((2, self.m0, 4))
         self.W = self.new_buffer((self.m0, 4))
-        one = _mont_limbs(1, field_modulus(self.field))
         ones = np.tile(one, (self.m0, 1))
         if isinstance(self.W, np.ndarray):
             self.W[:] = ones

@@ -62,3 +62,50 @@ def scalars_for(curve, n, seed, realistic=False):
         s[sm, 1:] = 0
         s[sm, 0] &= np.uint64(0xFF)
     return s
+
+
+def quotient_program(n_adv, n_fix, n_inst=0):
+    """A gate set in the style of the reference's circuit (circuits-halo2/src/encryption.rs:83-161: ECC-style multiplication
+    gates, a Pow5 S-box with a rotation, boolean / range checks behind fixed selectors, the lookup and permutation argument
+    constraints), folded with y: columns [0, n_adv) advice, [n_adv, n_adv + n_fix) fixed, then A', S', Z_lookup, Z_perm x3, then
+    the n_inst instance columns (equality-enabled in the reference's circuit: they enter through the last permutation chunk).
+    consts: [y, 5, 1, beta, gamma]"""
+    A = lambda i, r=0: ("col", i % n_adv, r)
+    Fx = lambda i, r=0: ("col", n_adv + i % n_fix, r)
+    X = n_adv + n_fix
+    I = lambda i: ("col", X + 6 + i % n_inst, 0)
+    ap, sp, zl = ("col", X, 0), ("col", X + 1, 0), ("col", X + 2, 0)
+    zp = [("col", X + 3 + c, 0) for c in range(3)]
+    prog = []
+    # every term after the first is folded in as  acc = acc * y + term
+    # multiplication gates  q (a b - c), eight of them
+    first = True
+    for g in range(8):
+        term = [Fx(g), A(g), A(g + 1), ("mul",), A(g + 2), ("sub",), ("mul",)]
+        prog.extend(term if first else [("scale", 0)] + term + [("add",)])
+        first = False
+    # Pow5 with a rotation  q (a^5 + 5 - b(omega X)), three of them
+    for g in range(3):
+        a = A(3 * g + 1)
+        prog.extend([("scale", 0), Fx(g + 3), a, a, ("mul",), a, ("mul",), a, ("mul",), a, ("mul",), ("const", 1), ("add",),
+                     ("col", (3 * g + 2) % n_adv, 1), ("sub",), ("mul",), ("add",)])
+    # boolean checks  q a (a - 1), four of them
+    for g in range(4):
+        a = A(g + 9)
+        prog.extend([("scale", 0), Fx(g + 4), a, a, ("const", 2), ("sub",), ("mul",), ("mul",), ("add",)])
+    # lookup: Z(omega X)(A' + beta)(S' + gamma) - Z(X)(A + beta)(S + gamma), and (A' - S')(A' - A'(omega^-1 X))
+    prog.extend([("scale", 0), ("col", X + 2, 1), ap, ("const", 3), ("add",), ("mul",), sp, ("const", 4), ("add",), ("mul",),
+                 zl, A(0), ("const", 3), ("add",), ("mul",), Fx(7), ("const", 4), ("add",), ("mul",), ("sub",), ("add",)])
+    prog.extend([("scale", 0), ap, sp, ("sub",), ap, ("col", X, -1), ("sub",), ("mul",), ("add",)])
+    # permutation, per chunk: Z(omega X) prod (v + beta s + gamma) - Z(X) prod (v + delta-term + gamma), two columns of each chunk written out
+    for c in range(3):
+        v0, v1 = (I(0), I(1)) if (n_inst and c == 2) else (A(2 * c), A(2 * c + 1))
+        prog.extend([("scale", 0), ("col", X + 3 + c, 1), v0, Fx(c), ("scale", 3), ("add",), ("const", 4), ("add",), ("mul",),
+                     v1, Fx(c + 1), ("scale", 3), ("add",), ("const", 4), ("add",), ("mul",),
+                     zp[c], v0, ("const", 4), ("add",), ("mul",), v1, ("const", 3), ("add",), ("mul",), ("sub",), ("add",)])
+    return prog
+
+
+def rotated_advice(n_adv):
+    """the advice columns quotient_program reads at the next row (the Pow5 gates): they are opened at x AND omega x"""
+    return sorted({(3 * g + 2) % n_adv for g in range(3)})

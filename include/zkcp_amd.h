@@ -90,6 +90,9 @@ typedef struct {
 #define ZK_MSM_FLAG_SLICE_REDUCE 2  /* bucket reduction by slices + multiplier (round 1) instead of row / column sums: A/B */
 #define ZK_MSM_FLAG_PRECOMPUTED 4   /* ONE bucket set over the handle's table of window multiples (zk_bases_precompute first): no per-window
                                      * reduction, no host Horner; whole MSMs over the whole handle only */
+#define ZK_MSM_FLAG_DEVICE_PARTIALS 8 /* diagnostic: the lazy-limb partial sums are converted to the caller's limb form on the device, the result
+                                       * is built from those, and every one is checked against the host's conversion: zk_msm_profile.reserved =
+                                       * mismatches (low 24 bits) | first differing conversion stage << 24 | its component << 28 */
 
 /* NTT plan knobs (process-wide, zk_ntt_configure).  Zero-initialise for defaults. */
 typedef struct {
@@ -108,7 +111,7 @@ typedef struct {
     int groups;      /* always 1 (a two-stream window-group pipeline was measured slower and removed) */
     int limb_bits;   /* bucket arithmetic of the call: 29 = lazy unsaturated limbs (9 x 29 bits; BLS12-381 14 x 28; pairs of those on G2), 32 = saturated words */
     float accumulate_kernel_ms;   /* msm_accumulate_kernel alone (accumulate_ms also covers the piece / segment combine kernels) */
-    int reserved;
+    int reserved;    /* ZK_MSM_FLAG_DEVICE_PARTIALS: see there; 0 otherwise */
 } zk_msm_profile;
 
 /* Sums over every MSM collected since the last reset (HIP events on the launch streams): what a bench needs when MSMs
@@ -215,6 +218,12 @@ int zk_ntt_coset_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const vo
  * shift ; best_fft on the extended domain), without storing or re-reading the padding.  log_in <= log_n. */
 int zk_ntt_extend_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, uint32_t log_in, const void *omega_mont_host,
                          int scale_by_n_inv, const void *g_pre_mont_host, const void *g_post_mont_host, void *hip_stream);
+
+/* ... out of place: the input src[0 .. 2^log_in) is read by the first pass and left untouched, the 2^log_n results land in dst
+ * (src == dst is the in-place form above; otherwise the buffers must not overlap).  halo2 keeps BOTH forms of every column
+ * (Lagrange values -> coefficients for the openings -> extended coset for the quotient): no copy in between. */
+int zk_ntt_oop_device(zk_field_t f, const void *src_mont_dev, void *dst_mont_dev, uint32_t log_n, uint32_t log_in, const void *omega_mont_host,
+                      int scale_by_n_inv, const void *g_pre_mont_host, const void *g_post_mont_host, void *hip_stream);
 
 /* a[i] *= g^i, i < 2^log_n */
 int zk_coset_mul(zk_field_t f, void *a_mont_host, uint32_t log_n, const void *g_mont_host);

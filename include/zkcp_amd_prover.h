@@ -131,12 +131,22 @@ int zk_vec_fold_device(zk_field_t f, void *a_dev, uint64_t half, const void *c_m
 /* poly/multiopen/prover.rs: a[i] = a[i] * s + b[i] -- one Horner step of folding the polynomials queried at the same point set with
  * powers of x_1 (and the per-set quotients with x_4), on resident coefficient vectors.  s: Montgomery, host. */
 int zk_vec_muladd_device(zk_field_t f, void *a_dev, const void *b_dev, uint64_t n, const void *s_mont_host, void *hip_stream);
+/* ... out[i] = a[i] * s + b[i] into a third buffer (out == a or out == b allowed; otherwise disjoint): the first step of such a fold starts
+ * from two resident polynomials and must clobber neither (upstream clones; this saves the copy) */
+int zk_vec_muladd_to_device(zk_field_t f, void *out_dev, const void *a_dev, const void *b_dev, uint64_t n, const void *s_mont_host, void *hip_stream);
 /* arithmetic.rs eval_polynomial: p(x) = sum_i coeffs[i] x^i for a resident coefficient vector (the evaluations create_proof
  * writes to the transcript: every committed polynomial at x and at its rotations omega^r x).  x, the result: Montgomery, host. */
 int zk_poly_eval_device(zk_field_t f, const void *coeffs_dev, uint64_t n, const void *x_mont_host, void *out_mont_host, void *hip_stream);
 /* ... `count` polynomials of n coefficients (polynomial q at element offset q * stride_elems) at the same x: one launch, one copy */
 int zk_poly_eval_batch_device(zk_field_t f, const void *coeffs_dev, uint64_t n, uint32_t count, uint64_t stride_elems, const void *x_mont_host,
                               void *out_mont_host, void *hip_stream);
+/* out[i] = x^i, i < n: the vector b of poly/commitment/prover.rs create_proof (powers of x_3), built from per-call power tables of x */
+int zk_vec_powers_device(zk_field_t f, void *out_dev, uint64_t n, const void *x_mont_host, void *hip_stream);
+/* arithmetic.rs kate_division(a, x): the quotient of (a(X) - a(x)) / (X - x) as n coefficients (upstream returns n - 1 and
+ * poly/multiopen/prover.rs resizes to n: q[n - 1] = 0); the multiopen argument divides every point set's folded polynomial by
+ * (X - x_j) for each point of the set in turn, which leaves the quotient by the set's vanishing polynomial.  q_dev == a_dev
+ * (in place) or disjoint.  A three-phase suffix scan (q[j] = a[j + 1] + x q[j + 1]), ~3 products per coefficient. */
+int zk_kate_division_device(zk_field_t f, const void *a_dev, void *q_dev, uint64_t n, const void *x_mont_host, void *hip_stream);
 /* ... and the generator side (parallel_generator_collapse): g[i] <- affine(g[i] + [u] g[i + half]), i < half; g holds
  * 2 * half affine points (x, y) Montgomery on the device, u an element of the curve's scalar field (Montgomery, host) */
 int zk_ipa_fold_bases_device(zk_curve_t c, void *g_affine_dev, uint64_t half, const void *u_mont_host, void *hip_stream);

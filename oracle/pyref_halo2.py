@@ -90,6 +90,35 @@ def ipa_argument(curve, p_prime, b, g, challenges):
     return rounds, p_prime[0], b[0], g[0]
 
 
+def kate_division(field, a, b):
+    """arithmetic.rs kate_division(a, b): the loop as published -- b = -b; q = [0] * (len(a) - 1); tmp = 0; walking q and a from
+    the top: lead = a_i - tmp; q_i = lead; tmp = lead * b -- i.e. the quotient of a(X) / (X - b), remainder dropped"""
+    p = pyref.FIELDS[field][0]
+    nb = (-b) % p
+    q = [0] * (len(a) - 1)
+    tmp = 0
+    for j in range(len(q) - 1, -1, -1):
+        lead = (a[j + 1] - tmp) % p
+        q[j] = lead
+        tmp = lead * nb % p
+    return q
+
+
+def multiopen_quotient(field, q_polys, point_sets, x_2, n):
+    """poly/multiopen/prover.rs create_proof, from the per-set folded polynomials to q'(X): every set's polynomial divided by
+    (X - point) for each point of the set (kate_division folded over the points), resized to n, and the sets combined as
+    q' = q' x_2 + poly"""
+    p = pyref.FIELDS[field][0]
+    acc = None
+    for poly, points in zip(q_polys, point_sets):
+        cur = list(poly)
+        for pt in points:
+            cur = kate_division(field, cur, pt)
+        cur = cur + [0] * (n - len(cur))
+        acc = cur if acc is None else [(u * x_2 + v) % p for u, v in zip(acc, cur)]
+    return acc
+
+
 def eval_program(field, program, columns, consts, n_ext, rot_scale, i):
     """the quotient evaluator's stack program at row i of the extended domain (see include/zkcp_amd_prover.h, zk_expr_*):
     ops: ("col", column, rotation) ("const", index) ("add",) ("sub",) ("mul",) ("neg",) ("scale", index)"""

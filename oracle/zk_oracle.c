@@ -158,9 +158,10 @@ static void *gen_worker(void *arg) {
 }
 EXPORT void orc_fixed_base_mul(int c, const uint64_t *scalars, size_t n, int threads, uint64_t *aff_out) {
     if (threads < 1) threads = 1;
-    pthread_t th[64];
-    genjob jobs[64];
-    if (threads > 64) threads = 64;
+    pthread_t th[256];
+    genjob jobs[256];
+    if (threads > 256) threads = 256;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
     for (int t = 0; t < threads; t++) {
         jobs[t] = (genjob){c, scalars, aff_out, n * t / threads, n * (t + 1) / threads};
         pthread_create(&th[t], NULL, gen_worker, &jobs[t]);
@@ -288,12 +289,12 @@ static void butterflies(const fctx_4 *f, fe_4 *a, const fe_4 *omega, int logn, i
     fe_one_4(f, &tw[0]);
     for (size_t i = 1; i < n / 2; i++) fe_mul_4(f, &tw[i], &tw[i - 1], omega);
     if (threads < 1) threads = 1;
-    if (threads > 64) threads = 64;
+    if (threads > 256) threads = 256;
     if ((size_t)threads > n / 2) threads = 1;
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, NULL, threads);
-    pthread_t th[64];
-    nttjob jobs[64];
+    pthread_t th[256];
+    nttjob jobs[256];
     for (int t = 0; t < threads; t++) {
         jobs[t] = (nttjob){f, a, tw, logn, dit, t, threads, &bar};
         if (t) pthread_create(&th[t], NULL, ntt_worker, &jobs[t]);

@@ -21,8 +21,12 @@ CURVE_IDS = ["Pallas", "Vesta", "Bn254G1", "Bls381G1", "Bn254G2", "Bls381G2"]
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO):
-        subprocess.check_call(["make", "-C", _DIR] + (["-B"] if force else []))
+    # make decides what is stale (the prebuilt library travels to the GPU box with the snapshot; a box without make keeps it)
+    try:
+        subprocess.check_call(["make", "-s", "-C", _DIR] + (["-B"] if force else []))
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(_SO):
+            raise
 
 
 _lib = None

@@ -178,6 +178,9 @@ extern "C" {
     pub fn zk_ntt_extend_device(f: c_int, a_mont_dev: *mut c_void, log_n: u32, log_in: u32, omega_mont_host: *const c_void,
                                 scale_by_n_inv: c_int, g_pre_mont_host: *const c_void, g_post_mont_host: *const c_void,
                                 hip_stream: *mut c_void) -> c_int;
+    pub fn zk_ntt_oop_device(f: c_int, src_mont_dev: *const c_void, dst_mont_dev: *mut c_void, log_n: u32, log_in: u32,
+                             omega_mont_host: *const c_void, scale_by_n_inv: c_int, g_pre_mont_host: *const c_void,
+                             g_post_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_coset_mul(f: c_int, a_mont_host: *mut c_void, log_n: u32, g_mont_host: *const c_void) -> c_int;
     pub fn zk_coset_mul_device(f: c_int, a_mont_dev: *mut c_void, log_n: u32, g_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_vec_op_device(f: c_int, op: c_int, a_dev: *mut c_void, b_dev: *const c_void, c_dev: *const c_void, n: u64,
@@ -234,6 +237,10 @@ extern "C" {
     pub fn zk_poly_eval_device(f: c_int, coeffs_dev: *const c_void, n: u64, x_mont_host: *const c_void, out_mont_host: *mut c_void,
                                hip_stream: *mut c_void) -> c_int;
     pub fn zk_vec_muladd_device(f: c_int, a_dev: *mut c_void, b_dev: *const c_void, n: u64, s_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn zk_vec_muladd_to_device(f: c_int, out_dev: *mut c_void, a_dev: *const c_void, b_dev: *const c_void, n: u64, s_mont_host: *const c_void,
+                                   hip_stream: *mut c_void) -> c_int;
+    pub fn zk_vec_powers_device(f: c_int, out_dev: *mut c_void, n: u64, x_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn zk_kate_division_device(f: c_int, a_dev: *const c_void, q_dev: *mut c_void, n: u64, x_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_poly_eval_batch_device(f: c_int, coeffs_dev: *const c_void, n: u64, count: u32, stride_elems: u64, x_mont_host: *const c_void,
                                      out_mont_host: *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_vec_fold_device(f: c_int, a_dev: *mut c_void, half: u64, c_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;

@@ -94,6 +94,86 @@ def _worker(rank, world, port, emu_path, q):
     q.put((rank, ok))
 
 
+def _quotient_worker(rank, world, port, emu_path, q):
+    """the extended coset in `world` sub-cosets: every rank transforms every column onto ITS sub-coset (one transform of size
+    extended_len / world per column), evaluates the quotient program there (rotations stay inside the sub-coset), divides by the
+    vanishing polynomial's values on it, and ONE all_gather (dist.gather_parts) assembles h -- bit-equal to the unsharded path"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contangle_zkcp_amd as zk
+    from contangle_zkcp_amd import dist as zkdist, synth
+    import parity_suite as ps
+    zk.load(path=emu_path)
+    zk.init(0)
+    name, k, j = "PallasFp", 5, 9
+    dom = zk.halo2.EvaluationDomain(name, j, k)
+    n, ne, ek = dom.n, dom.extended_len(), dom.extended_k
+    n_adv, n_fix, n_inst = 13, 8, 3
+    prog = synth.quotient_program(n_adv, n_fix, n_inst)
+    ncols = n_adv + n_fix + 6 + n_inst
+    coeffs = [ps.rand_field(name, n, 700 + c) for c in range(ncols)]
+    consts = ps.rand_field(name, 5, 777)
+    # unsharded reference (same library, whole coset)
+    whole = []
+    for c in coeffs:
+        buf = np.zeros((ne, 4), dtype=np.uint64)
+        dom.coeff_to_extended(buf, coeffs=c.copy())
+        whole.append(buf)
+    h_ref = np.zeros((ne, 4), dtype=np.uint64)
+    zk.halo2.evaluate_expression(name, prog, whole, consts, ek, 1 << (ek - k), h_ref)
+    dom.divide_by_vanishing_poly(h_ref)
+    # this rank's sub-coset
+    m = dom.part_len(world)
+    mine = []
+    for c in coeffs:
+        buf = np.zeros((m, 4), dtype=np.uint64)
+        dom.coeff_to_extended_part(c.copy(), buf, rank, world)
+        mine.append(buf)
+    h_part = np.zeros((m, 4), dtype=np.uint64)
+    zk.halo2.evaluate_expression(name, prog, mine, consts, m.bit_length() - 1, dom.rot_scale_part(world), h_part)
+    dom.divide_by_vanishing_poly_part(h_part, rank, world)
+    h = np.zeros((ne, 4), dtype=np.uint64)
+    zkdist.gather_parts(h_part, h)
+    ok = bool((h == h_ref).all()) and bool((h_part == h_ref[rank::world]).all())
+    # ... and the coefficients of h agree as well
+    a, b = h.copy(), h_ref.copy()
+    dom.extended_to_coeff(a)
+    dom.extended_to_coeff(b)
+    ok &= bool((a == b).all())
+    zk.shutdown()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+def _run(worker, world):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("zk_build", os.path.join(ROOT, "contangle-zkcp_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    emu = b.build_emu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, emu, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert res == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_quotient_coset_sharded_gloo(world):
+    _run(_quotient_worker, world)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_msm_sharded_gloo(world):
     import importlib.util

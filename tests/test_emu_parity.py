@@ -121,6 +121,12 @@ def test_msm_axis_reduce(zk):
     ps.check_msm_axis_reduce(zk, "Pallas", 300, [16, 15], windows=(0, 2))
 
 
+def test_msm_device_side_partial_conversion(zk):
+    ps.check_msm_device_partials(zk, "Bn254G1", n=120, window_bits_list=(0, 5))
+    ps.check_msm_device_partials(zk, "Bls381G2", n=40, window_bits_list=(4,))
+    ps.check_msm_device_partials(zk, "Vesta", n=90, window_bits_list=(3,))
+
+
 def test_fixed_base_msm(zk):
     ps.check_fixed_base_msm(zk, "Vesta", 21)
     ps.check_fixed_base_msm(zk, "Bn254G2", 13)
@@ -183,6 +189,12 @@ def test_halo2_eval_polynomial(zk):
     ps.check_eval_polynomial(zk, "Bls381Fr", sizes=(3, 300))
 
 
+def test_halo2_kate_division(zk):
+    ps.check_kate_division(zk, "PallasFp")
+    ps.check_kate_division(zk, "Bls381Fr", sizes=(3, 4100))
+    ps.check_kate_division_at_size(zk, "PallasFq", 14)
+
+
 def test_halo2_ipa(zk):
     ps.check_ipa(zk, "Vesta", 4)
     ps.check_ipa(zk, "Pallas", 2)
@@ -191,6 +203,14 @@ def test_halo2_ipa(zk):
 
 def test_halo2_expression(zk):
     ps.check_expression(zk, "PallasFp", 4)
+
+
+def test_halo2_work_list_shapes_small(zk):
+    """the at-size checks of the GPU tier (bench program on sampled rows; IPA in the exponent with a collapse), at emulator sizes"""
+    assert ps.check_expression_at_size(zk, "PallasFp", 4, 3, samples=20) >= 20
+    assert ps.check_expression_at_size(zk, "PallasFp", 5, 3, samples=20, parts=4) >= 20      # one sub-coset of a 4-way sharded quotient
+    ps.check_ipa_at_size(zk, "Vesta", 6, 2, survivors=4)
+    ps.check_ipa_at_size(zk, "Pallas", 4, 3, survivors=2)
 
 
 def test_ntt_saturated_limbs_path(zk, ntt_plan):
