@@ -66,6 +66,30 @@ def load_traffic(kernel, workload):
     return e.get("hbm_bytes_per_launch"), e.get("valu_wave_insts_per_launch")
 
 
+def host_cores():
+    """CPUs this process may actually use: the scheduler affinity and the cgroup CPU quota of the box, not the host's core count
+    (a one-GPU box of the pool shows 256 logical CPUs and grants about 16)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, int(q / p + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 class Env:
     pass
 
@@ -93,6 +117,8 @@ def setup():
                     help="single-GPU A/B: the MSMs use ONE bucket set over a table of window multiples of the bases (zk_bases_precompute, 16 x the "
                          "key in HBM) instead of one bucket set per window")
     ap.add_argument("--ntt-limbs", type=int, default=0, choices=[0, 32], help="0: lazy 29-bit limbs inside the NTT tiles (default); 32: saturated words (A/B)")
+    ap.add_argument("--expr-limbs", type=int, default=0, choices=[0, 32],
+                    help="halo2 work-list, quotient expression: 0 = lazy 29-bit limbs over cosets written in the R' radix (default); 32 = the saturated evaluator (A/B)")
     args = ap.parse_args()
 
     import numpy as np
@@ -196,7 +222,7 @@ def rooflines(e, workload_key):
         ach = t["algorithmic_bytes"] / (t["kernel_ms"] * 1e-3) / 1e9
         traffic, valu = load_traffic("ntt_pass_kernel", workload_key)
         out["ntt_pass_kernel"] = {
-            "kernel": "ntt_pass_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "ntt_pass_kernel" if e.args.ntt_limbs == 32 else "ntt_pass29_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "launches": t["launches"], "avg_launch_us": t["kernel_ms"] / t["launches"] * 1e3,
             "algorithmic_bytes_per_launch": t["algorithmic_bytes"] / t["launches"], "kernel_ms_total": t["kernel_ms"],
@@ -221,7 +247,7 @@ def emit(e, line, roofs):
             mads = {"Vesta": 135, "Pallas": 135, "Bn254G1": 162, "Bls381G1": 392, "Bn254G2": 4 * 81 + 2 * 81, "Bls381G2": 4 * 196 + 2 * 196}.get(
                 line["config"].get("msm_curve", ""), None)
             if mads:
-                adds = line["config"]["msm_points"] * line["config"]["msm_windows_done"]
+                adds = line["config"]["msm_points"] * line["config"]["msm_windows_done"] * acc["msms"] / max(1, acc["launches"])   # a launch sums up to 4 scalar vectors
                 a = adds * 10 * mads / (acc["avg_launch_us"] * 1e-6) / 1e12
                 line["int_mad_roofline"] = {"achieved_tmad_s": a, "peak_tmad_s": 33.7, "frac": a / 33.7, "mads_per_field_mul": mads,
                                             "note": "mixed adds x 10 field mul x MAD-equivalents per mul over accumulate-kernel time"}
@@ -334,8 +360,13 @@ def bench_halo2(e):
     d_ipa = [newbuf(n) for _ in range(2)]
     d_S, d_W = torch.zeros((2, n, 4), dtype=torch.int64, device="cuda"), newbuf(n)    # IPA scalar / weight buffers, reused every step
     prog = e.synth.quotient_program(NCOL, N_FIXED, N_INST)
+    lazy_expr = a.expr_limbs != 32
+    if lazy_expr:                                     # key material in the evaluator's radix, once
+        for d in d_fixed_cos:
+            H.to_lazy_form(sfield, d, stream=e.st)
     main = torch.cuda.current_stream()
     side = main if a.serial else torch.cuda.Stream()
+    ev_zp, ev_zl = torch.cuda.Event(), torch.cuda.Event()
     result = {}
     PH = ("advice", "lookup", "permutation", "quotient", "evaluations", "multiopen", "opening")
     phase_ms = dict.fromkeys(PH, 0.0)
@@ -346,7 +377,7 @@ def bench_halo2(e):
         """Lagrange column -> coefficients (out of place, kept for the openings) -> this rank's sub-coset"""
         co = d_coef[row[nm]]
         dom.lagrange_to_coeff(src, stream=stream, out=co)
-        dom.coeff_to_extended_part(co, d_cos[nm], part, parts, stream=stream)
+        dom.coeff_to_extended_part(co, d_cos[nm], part, parts, stream=stream, lazy_out=lazy_expr)
 
     collapse_at = {int(v) for v in str(a.ipa_collapse_after).split(",") if v.strip()}
     pre = a.precomputed and e.world == 1
@@ -372,6 +403,9 @@ def bench_halo2(e):
             cls_sum[name][kk] += v
 
     def step(i, timed_):
+        # Phase times are host timestamps taken where the host holds a phase's commitments (a transcript point); there is no
+        # device-wide barrier between the phases: the NTT chains float on the side stream -- the next phase's MSMs do not need
+        # them -- until the quotient reads the cosets.  (--serial: everything on one stream.)
         t0 = time.perf_counter()
         # ---- 0 + 1 instance and advice columns: NTT chains on the side stream beside one batched commitment call
         side.wait_stream(main)
@@ -380,20 +414,14 @@ def bench_halo2(e):
                 chain(("inst", c), d_lag[c], side.cuda_stream)
             for c in range(NCOL):
                 chain(("adv", c), d_lag[N_INST + c], side.cuda_stream)
+            chain(("lk", "A'"), d_lookup[2], side.cuda_stream)     # (the permuted columns are inputs here: the sort is a CPU step)
+            chain(("lk", "S'"), d_lookup[3], side.cuda_stream)
         result["commitments"] = commit_batch(g_lagrange, d_lag)
         if "prof" not in result:
             result["prof"] = zk.msm_last_profile()
-        main.wait_stream(side)
-        torch.cuda.synchronize()
         t1 = time.perf_counter()
         # ---- 2 lookup: the permuted columns
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            chain(("lk", "A'"), d_lookup[2], side.cuda_stream)
-            chain(("lk", "S'"), d_lookup[3], side.cuda_stream)
         commit_batch(g_lagrange, d_lookup[2:4])
-        main.wait_stream(side)
-        torch.cuda.synchronize()
         t2 = time.perf_counter()
         # ---- 3 permutation: chunk c + 1 continues from the last value of chunk c; columns = 13 advice + 3 instance
         z_first = None
@@ -402,54 +430,44 @@ def bench_halo2(e):
             lo, hi = c * PERM_CHUNK, min(N_PERM_COLS, (c + 1) * PERM_CHUNK)
             z_first = H.permutation_product(sfield, pcols[lo:hi], d_sigma[lo:hi], beta, gamma, delta, k, d_zp[c], first_column_index=lo,
                                             z_first=z_first, stream=e.st)
-        side.wait_stream(main)
+        ev_zp.record(main)
+        side.wait_event(ev_zp)
         with torch.cuda.stream(side):
             for c in range(3):
                 chain(("zp", c), d_zp[c], side.cuda_stream)
         commit_batch(g_lagrange, d_zp)
-        main.wait_stream(side)
-        torch.cuda.synchronize()
         t3 = time.perf_counter()
         # ---- 4 lookup product
         H.lookup_product(sfield, d_lookup[0], d_lookup[1], d_lookup[2], d_lookup[3], beta, gamma, d_zl, stream=e.st)
-        side.wait_stream(main)
+        ev_zl.record(main)
+        side.wait_event(ev_zl)
         with torch.cuda.stream(side):
             chain(("lk", "Z"), d_zl, side.cuda_stream)
         commit(g_lagrange, d_zl)
-        main.wait_stream(side)
-        torch.cuda.synchronize()
         t4 = time.perf_counter()
         # ---- 5 vanishing argument's random polynomial, 6 quotient
         commit(g_coeff, d_coef[row[("random", 0)]])
+        main.wait_stream(side)                                      # every coset (and coefficient form) is complete from here on
         ext_cols = ([d_cos[("adv", c)] for c in range(NCOL)] + d_fixed_cos + [d_cos[("lk", "A'")], d_cos[("lk", "S'")], d_cos[("lk", "Z")]]
                     + [d_cos[("zp", c)] for c in range(3)] + [d_cos[("inst", c)] for c in range(N_INST)])
-        H.evaluate_expression(sfield, prog, ext_cols, consts, ext - (parts.bit_length() - 1), rsc, d_hpart, stream=e.st)
+        H.evaluate_expression(sfield, prog, ext_cols, consts, ext - (parts.bit_length() - 1), rsc, d_hpart, stream=e.st, lazy=lazy_expr)
         dom.divide_by_vanishing_poly_part(d_hpart, part, parts, stream=e.st)
         if parts > 1:
             e.zkdist.gather_parts(d_hpart, d_h, stream=main)
         dom.extended_to_coeff(d_h, stream=e.st)
         pieces = d_h.view(N_H_PIECES, n, 4)
         commit_batch(g_coeff, pieces)
-        torch.cuda.synchronize()
         t5 = time.perf_counter()
         # ---- 7 evaluations: h(X) = sum_i x^(n i) h_i, then every committed polynomial at x and at its rotations
-        hrow = d_coef[row[("h", 0)]]
-        H.vec_muladd(sfield, pieces[N_H_PIECES - 1], pieces[N_H_PIECES - 2], xn, stream=e.st, out=hrow)
-        for q in range(N_H_PIECES - 3, -1, -1):
-            H.vec_muladd(sfield, hrow, pieces[q], xn, stream=e.st)
+        H.vec_fold_many(sfield, d_coef[row[("h", 0)]], pieces, xn, stream=e.st, reverse=True)
         result["evals"] = [H.eval_polynomials(sfield, d_coef, x, stream=e.st),
                            H.eval_polynomials(sfield, d_coef[sets[1][0]:], x_next, stream=e.st),
                            H.eval_polynomials(sfield, d_coef[sets[2][0]:sets[2][0] + sets[2][1]], x_prev, stream=e.st),
                            H.eval_polynomials(sfield, d_coef[sets[3][0]:], x_last, stream=e.st)]
         t6 = time.perf_counter()
         # ---- 8 multiopen
-        for s_, (first, cnt, pts) in enumerate(sets):
-            if cnt == 1:
-                d_q[s_].copy_(d_coef[first])
-            else:
-                H.vec_muladd(sfield, d_coef[first], d_coef[first + 1], x1, stream=e.st, out=d_q[s_])
-                for q in range(2, cnt):
-                    H.vec_muladd(sfield, d_q[s_], d_coef[first + q], x1, stream=e.st)
+        for s_, (first, cnt, pts) in enumerate(sets):          # each set's polynomials folded with x_1: one pass per set
+            H.vec_fold_many(sfield, d_q[s_], d_coef[first:first + cnt], x1, stream=e.st)
         for s_, (first, cnt, pts) in enumerate(sets):          # q' = q' x_2 + (set polynomial / prod (X - point))
             dst = d_qprime if s_ == 0 else d_tmp
             H.kate_division(sfield, d_q[s_], pts[0], out=dst, stream=e.st)
@@ -461,7 +479,6 @@ def bench_halo2(e):
         result["q_evals"] = H.eval_polynomials(sfield, d_q, x3, stream=e.st)
         for s_ in range(len(sets)):                             # p = q' x_4^4 + ... : one Horner step per set
             H.vec_muladd(sfield, d_qprime, d_q[s_], x4, stream=e.st)
-        torch.cuda.synchronize()
         t7 = time.perf_counter()
         if timed_:
             take_class("commit")
@@ -564,66 +581,76 @@ def bench_halo2(e):
 
 
 def cpu_baseline_halo2(e, curve, sfield, k, ext, d_pts, col0, gpu_commit0, counts):
-    """The oracle ('port': CPU restatements of halo2_proofs 0.2 best_multiexp -- chunk per thread over ALL host cores -- ,
-    best_fft, and per-element field / curve arithmetic) timed on this box on a bounded sample of the same work-list:
-    ONE commitment (both reference MSM algorithms, the faster is used), ONE best_fft at 2^k and ONE at 2^(k+3) (all cores, and one
-    thread for the scaling figure), 2^20 field products on one thread, 2^17 point multiplications on all cores (and 2^10 on one
-    thread); the step is assembled from the counts of each kind, with perfect scaling over the cores assumed for the per-element
-    work.  Also a last bit-exact check of the GPU's first commitment."""
+    """The oracle ('port': CPU restatements of halo2_proofs 0.2 best_multiexp -- chunk per thread -- , best_fft, and per-element
+    field / curve arithmetic) timed on this box on a bounded sample of the same work-list: ONE commitment (both reference MSM
+    algorithms, the faster is used), ONE best_fft at 2^k and ONE at 2^(k+3), 2^k field products on one thread, 2^10 point
+    multiplications on one thread and 2^17 on all threads.  `cores` = the CPUs this process may use (affinity / cgroup quota, not
+    the host's core count); the embarrassingly parallel point multiplications also give the MEASURED parallel speed-up, and the
+    threaded routines run with both thread counts (detected cores, measured speed-up) -- the faster time is used.  The step is
+    assembled from the counts of each kind; the per-element field work is divided by the measured speed-up.  Also a last
+    bit-exact check of the GPU's first commitment."""
     from oracle import zk_oracle as orc
     np, zk = e.np, e.zk
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     n = 1 << k
     pts = d_pts.cpu().numpy().view(np.uint64)
-    t0 = time.perf_counter()
-    exp = orc.msm_halo2(curve, pts, col0, threads=cores)
-    t_h2 = time.perf_counter() - t0
-    canon = orc.from_mont(sfield, col0)
-    ark_threads = min(cores, -(-255 // orc.ark_window_bits(n)))
-    t0 = time.perf_counter()
-    exp_ark = orc.msm_ark(curve, pts, canon, threads=ark_threads)
-    t_ark = time.perf_counter() - t0
-    w, w_ext = zk.root_of_unity(sfield, k), zk.root_of_unity(sfield, ext)
-    t0 = time.perf_counter()
-    orc.halo2_best_fft(sfield, col0, w, k, threads=cores)
-    t_n = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    orc.halo2_best_fft(sfield, col0, w, k, threads=1)
-    t_n1 = time.perf_counter() - t0
-    big = e.synth.rand_field(sfield, 1 << ext, 0xF00D)
-    t0 = time.perf_counter()
-    orc.halo2_best_fft(sfield, big, w_ext, ext, threads=cores)
-    t_e = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    orc.to_mont(sfield, col0)                                  # one Montgomery product per element, one thread, 2^k elements
-    t_mul = (time.perf_counter() - t0) / n
+
+    def best(fn, counts_):
+        out, tbest, thr = None, None, None
+        for t in counts_:
+            t0 = time.perf_counter()
+            r = fn(t)
+            dt = time.perf_counter() - t0
+            if tbest is None or dt < tbest:
+                out, tbest, thr = r, dt, t
+        return out, tbest, thr
+
     ks1 = e.synth.scalars_for(curve, 1 << 10, 78)
     t0 = time.perf_counter()
     orc.fixed_base_mul(curve, ks1, threads=1)                  # 255-bit double-and-add per point, one thread
     t_pmul1 = (time.perf_counter() - t0) / (1 << 10)
     ks = e.synth.scalars_for(curve, 1 << 17, 77)
     t0 = time.perf_counter()
-    orc.fixed_base_mul(curve, ks, threads=cores)               # ... all cores, 2^17 points (>= 512 per thread)
+    orc.fixed_base_mul(curve, ks, threads=min(256, cores))     # ... all threads, 2^17 points (>= 512 per thread)
     t_pmul = (time.perf_counter() - t0) / (1 << 17)
+    speedup = max(1.0, t_pmul1 / t_pmul)                       # what the box really grants
+    tc = sorted({min(256, cores), max(1, min(256, int(speedup + 0.5)))}, reverse=True)
+    exp, t_h2, thr_h2 = best(lambda t: orc.msm_halo2(curve, pts, col0, threads=t), tc)
+    canon = orc.from_mont(sfield, col0)
+    ark_threads = min(cores, -(-255 // orc.ark_window_bits(n)))
+    t0 = time.perf_counter()
+    exp_ark = orc.msm_ark(curve, pts, canon, threads=ark_threads)
+    t_ark = time.perf_counter() - t0
+    w, w_ext = zk.root_of_unity(sfield, k), zk.root_of_unity(sfield, ext)
+    _, t_n, thr_n = best(lambda t: orc.halo2_best_fft(sfield, col0, w, k, threads=t), tc)
+    t0 = time.perf_counter()
+    orc.halo2_best_fft(sfield, col0, w, k, threads=1)
+    t_n1 = time.perf_counter() - t0
+    big = e.synth.rand_field(sfield, 1 << ext, 0xF00D)
+    _, t_e, thr_e = best(lambda t: orc.halo2_best_fft(sfield, big, w_ext, ext, threads=t), tc)
+    t0 = time.perf_counter()
+    orc.to_mont(sfield, col0)                                  # one Montgomery product per element, one thread, 2^k elements
+    t_mul = (time.perf_counter() - t0) / n
     t_msm = min(t_h2, t_ark)
     muls_products = n * (4 * 8 + 3 * (4 * PERM_CHUNK + 8))      # factors, batched inversion, scan: lookup + three permutation chunks
     muls_expr = (1 << ext) * counts["expr_muls"]               # the products of the quotient program, at every row of the extended domain
     muls_open = n * (counts["evals"] + counts["folds"] + counts["kate"] + 2)   # Horner evaluations, folds, kate_division, b: one product per coefficient each
-    t_field = (muls_products + muls_expr + muls_open) * t_mul / cores
+    t_field = (muls_products + muls_expr + muls_open) * t_mul / speedup
     # IPA: MSMs of 2 * (n/2 + n/4 + ...) = 2n points ~ two full MSMs; n point multiplications for the generator folds
     t_ipa = 2 * t_msm + n * t_pmul
     t_step = counts["msm"] * t_msm + counts["ntt_k"] * t_n + counts["ntt_ext"] * t_e + t_field + t_ipa
     ok = bool((zk.point_to_affine(curve, gpu_commit0) == exp).all() and (exp == exp_ark).all())
     return {"value": n / t_step, "unit": "constraints/s", "cores": cores, "kind": "port",
-            "sample": "best_multiexp 2^%d (halo2 chunk-per-thread, %d threads: %.3f s; ark window-parallel, %d threads: %.3f s; faster one used) ; best_fft 2^%d %.3f s "
-                      "(%d threads; %.3f s on one: x%.1f -- upstream's serial bit-reversal and twiddle table bound it), 2^%d %.3f s ; field product %.0f ns (one thread, 2^%d products) ; "
-                      "point multiplication %.0f us on one thread, %.2f us per point on %d threads (2^17 points) ; "
-                      "step = %d MSMs + %d + %d FFTs + %.2g products / %d cores + IPA (2 MSM + 2^%d point multiplications) = %.2f s"
-                      % (k, cores, t_h2, ark_threads, t_ark, k, t_n, cores, t_n1, t_n1 / t_n, ext, t_e, t_mul * 1e9, k, t_pmul1 * 1e6, t_pmul * 1e6, cores,
-                         counts["msm"], counts["ntt_k"], counts["ntt_ext"], muls_products + muls_expr + muls_open, cores, k, t_step),
+            "sample": "host: %d logical CPUs, %d usable (affinity / cgroup), measured parallel speed-up x%.1f (2^17 point multiplications: %.0f us on one thread, %.2f us per point "
+                      "on %d threads) ; best_multiexp 2^%d: halo2 chunk-per-thread %.3f s (%d threads), ark window-parallel %.3f s (%d threads), faster one used ; best_fft 2^%d %.3f s "
+                      "(%d threads; %.3f s on one: x%.1f -- upstream's serial bit-reversal and twiddle table bound it), 2^%d %.3f s (%d threads) ; field product %.0f ns (one thread, 2^%d "
+                      "products) ; step = %d MSMs + %d + %d FFTs + %.2g products / %.1f + IPA (2 MSM + 2^%d point multiplications) = %.2f s"
+                      % (os.cpu_count() or 1, cores, speedup, t_pmul1 * 1e6, t_pmul * 1e6, min(256, cores), k, t_h2, thr_h2, t_ark, ark_threads, k, t_n, thr_n, t_n1, t_n1 / t_n,
+                         ext, t_e, thr_e, t_mul * 1e9, k, counts["msm"], counts["ntt_k"], counts["ntt_ext"], muls_products + muls_expr + muls_open, speedup, k, t_step),
             "msm_mops": n / t_msm / 1e6, "msm_s": {"halo2_chunked": t_h2, "ark_window_parallel": t_ark},
-            "fft_s": {"2p%d_all_cores" % k: t_n, "2p%d_one_thread" % k: t_n1, "2p%d_all_cores" % ext: t_e},
-            "point_mul_us": {"one_thread": t_pmul1 * 1e6, "per_point_all_cores": t_pmul * 1e6},
+            "fft_s": {"2p%d" % k: t_n, "2p%d_one_thread" % k: t_n1, "2p%d" % ext: t_e},
+            "point_mul_us": {"one_thread": t_pmul1 * 1e6, "per_point_all_threads": t_pmul * 1e6},
+            "parallel_speedup_measured": speedup, "logical_cpus": os.cpu_count() or 1,
             "step_s": {"msm": counts["msm"] * t_msm, "fft": counts["ntt_k"] * t_n + counts["ntt_ext"] * t_e, "field": t_field, "ipa": t_ipa},
             "gpu_result_matches": ok}
 
@@ -681,7 +708,7 @@ def cpu_baseline_column(e, curve, sfield, logn, d_pts, sc_host, a_host, omega, g
     """one full step on the host cores: the faster of the two reference MSM algorithms + best_fft, all cores"""
     from oracle import zk_oracle as orc
     np, zk = e.np, e.zk
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     n = 1 << logn
     pts = d_pts.cpu().numpy().view(np.uint64)
     ark_threads = min(cores, -(-255 // orc.ark_window_bits(n)))
@@ -765,7 +792,7 @@ def cpu_baseline_groth16(e, g1, g2, fr, logn, d_b1, d_b2, z_host, abc_host):
     the G2 MSM on a 2^18 prefix (scaled linearly); step = 7 NTTs + 3.75 G1 MSMs + 1 G2 MSM"""
     from oracle import zk_oracle as orc
     np = e.np
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     m = 1 << logn
     thr = min(cores, -(-255 // orc.ark_window_bits(m)))
     pts1 = d_b1.cpu().numpy().view(np.uint64)

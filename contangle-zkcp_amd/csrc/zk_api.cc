@@ -1178,6 +1178,36 @@ API int zk_poly_eval_batch_device(zk_field_t f, const void* c, uint64_t n, uint3
     });
     return ZK_ERR_INVALID_ARG;
 }
+API int zk_vec_fold_many_device(zk_field_t f, void* out, const void* first, int64_t stride_elems, uint32_t count, uint64_t n, const void* s,
+                                void* stream) {
+    if (!s || count == 0 || (n && (!out || !first || !aligned16(out) || !aligned16(first)))) return ZK_ERR_INVALID_ARG;
+    if (count > 1 && (stride_elems == 0 || (uint64_t)(stride_elems < 0 ? -stride_elems : stride_elems) < n)) return ZK_ERR_INVALID_ARG;
+    {   // out may be one of the sources (every lane reads all of its inputs before it writes) or disjoint from all of them
+        const intptr_t o = (intptr_t)out, len = (intptr_t)n * 32;
+        for (uint32_t i = 0; i < count; i++) {
+            const intptr_t a = (intptr_t)first + (intptr_t)i * stride_elems * 32;
+            if (a != o && a < o + len && o < a + len) return ZK_ERR_INVALID_ARG;
+        }
+    }
+    DEVICE_ENTRY(out);
+    FIELD_SWITCH(f, {
+        Fe<F> ss;
+        host_load(ss, s);
+        return vec_fold_many_run<F>((Fe<F>*)out, (const Fe<F>*)first, stride_elems, count, n, ss, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
+API int zk_ipa_fold_round_device(zk_field_t f, void* p, void* b, void* w, uint64_t half, uint64_t m0, const void* u, void* stream) {
+    if (!u || (half && (!p || !b || !aligned16(p) || !aligned16(b))) || (w && !aligned16(w))) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(p);
+    FIELD_SWITCH(f, {
+        Fe<F> uu;
+        host_load(uu, u);
+        if (fe_is_zero(uu)) return ZK_ERR_INVALID_ARG;
+        return ipa_fold_round_run<F>((Fe<F>*)p, (Fe<F>*)b, (Fe<F>*)w, half, m0, uu, (hipStream_t)stream);
+    });
+    return ZK_ERR_INVALID_ARG;
+}
 API int zk_vec_powers_device(zk_field_t f, void* out, uint64_t n, const void* x, void* stream) {
     if (!x || (n && (!out || !aligned16(out)))) return ZK_ERR_INVALID_ARG;
     DEVICE_ENTRY(out);
@@ -1298,6 +1328,15 @@ API int zk_expr_eval_device(zk_field_t f, const zk_expr_op* prog, uint32_t n_ops
     DEVICE_ENTRY(out);
     FIELD_SWITCH(f, return expr_eval_run<F>(dc, prog, n_ops, cols, n_cols, (const Fe<F>*)consts, n_consts, log_n, rot_scale, (Fe<F>*)out,
                                             (hipStream_t)stream));
+    return ZK_ERR_INVALID_ARG;
+}
+
+API int zk_expr_eval_lazy_device(zk_field_t f, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const void* consts,
+                                 uint32_t n_consts, uint32_t log_n, uint32_t rot_scale, void* out, void* stream) {
+    if (!prog || !out || !aligned16(out) || (n_cols && !cols) || (n_consts && !consts)) return ZK_ERR_INVALID_ARG;
+    DEVICE_ENTRY(out);
+    FIELD_SWITCH(f, return expr_eval_lazy_run<F>(dc, prog, n_ops, cols, n_cols, (const Fe<F>*)consts, n_consts, log_n, rot_scale, (Fe<F>*)out,
+                                                 (hipStream_t)stream));
     return ZK_ERR_INVALID_ARG;
 }
 

@@ -170,18 +170,23 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
     if (g_post) ZK_TRY(pow_tables<F>(dc, *g_post, logn, field, st, &tpost, lazy));
     const Fe<F>* tw = nullptr;
     ZK_TRY(tw_table<F>(dc, omega, logn, field, st, &tw, lazy));
+    // scale_flag: bit 0 = multiply by n^-1 ; bit 1 (ZK_NTT_OUT_R29) = leave the results as x R' mod p (R' = 2^261, the lazy-limb
+    // radix zk_expr_eval_lazy_device reads) instead of x R mod p: the last pass multiplies by 2^5 more
     Fe<F> scale;
     fe_one(scale);
-    if (scale_flag) {
+    if (scale_flag & 1) {
         Fe<F> nn;
         fe_zero(nn);
         nn.v[logn / 32] = 1u << (logn % 32);
         fe_to_mont(nn, nn);
         fe_inv(scale, nn);
     }
-    if (lazy) {   // the last pass always multiplies by `scale`: n^-1 (or 1) in R' form
+    {
         constexpr int SH = F29<F>::W * F29<F>::L - 32 * F::N;
-        for (int k = 0; k < SH; k++) fe_dbl(scale, scale);
+        if (scale_flag & 2)
+            for (int k = 0; k < SH; k++) fe_dbl(scale, scale);
+        if (lazy)   // the last pass always multiplies by `scale`: n^-1 (or 1) in R' form
+            for (int k = 0; k < SH; k++) fe_dbl(scale, scale);
     }
     NttPlan plan = ntt_plan(logn);
     Fe<F>* tmp = nullptr;
@@ -200,7 +205,7 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
         A.log_r = plan.rd[p];
         A.log_t = plan.log_t[p];
         A.last = (p == plan.nd - 1);
-        A.scale = A.last ? scale_flag : 0;
+        A.scale = (A.last && scale_flag) ? 1 : 0;
         A.nd = plan.nd;
         for (int i = 0; i < plan.nd; i++) A.rd[i] = plan.rd[i];
         A.pre = (p == 0 && g_pre) ? 1 : 0;

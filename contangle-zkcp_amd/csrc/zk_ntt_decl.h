@@ -40,6 +40,10 @@ int vec_muladd_run(Fe<F>* out, const Fe<F>* a, const Fe<F>* b, uint64_t n, const
 template <class F>
 int poly_eval_run(DeviceCtx& dc, const Fe<F>* c, uint64_t n, uint32_t count, uint64_t stride, const Fe<F>& x, int field, void* out_host, hipStream_t st);
 template <class F>
+int vec_fold_many_run(Fe<F>* out, const Fe<F>* first, int64_t stride, uint32_t count, uint64_t n, const Fe<F>& s, hipStream_t st);
+template <class F>
+int ipa_fold_round_run(Fe<F>* p, Fe<F>* b, Fe<F>* W, uint64_t half, uint64_t m0, const Fe<F>& u, hipStream_t st);
+template <class F>
 int vec_powers_run(DeviceCtx& dc, Fe<F>* out, uint64_t n, const Fe<F>& x, hipStream_t st);
 template <class F>
 int kate_division_run(DeviceCtx& dc, const Fe<F>* a, Fe<F>* q, uint64_t n, const Fe<F>& x, hipStream_t st);
@@ -56,6 +60,9 @@ int ipa_update_weights_run(Fe<F>* W, uint64_t m0, uint64_t bit, const Fe<F>& u, 
 template <class F>
 int expr_eval_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const Fe<F>* consts,
                   uint32_t n_consts, uint32_t log_n, uint32_t rot_scale, Fe<F>* out, hipStream_t st);
+template <class F>
+int expr_eval_lazy_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const Fe<F>* consts,
+                       uint32_t n_consts, uint32_t log_n, uint32_t rot_scale, Fe<F>* out, hipStream_t st);
 template <class F>
 int r1cs_matvec_run(const R1csMatrix& m, const Fe<F>* z, Fe<F>* out, uint64_t out_len, hipStream_t st);
 template <class F>

@@ -187,6 +187,28 @@ int scratch_pow_tables(StreamScratch& ss, const Fe<F>& x, uint32_t logn, hipStre
 }
 
 template <class F>
+int vec_fold_many_run(Fe<F>* out, const Fe<F>* first, int64_t stride, uint32_t count, uint64_t n, const Fe<F>& s, hipStream_t st) {
+    if (n == 0 || count == 0) return ZK_OK;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    ZK_LAUNCH((vec_fold_many_kernel<F>), (unsigned)blocks, 256, 0, st, out, first, stride, count, n, s);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+template <class F>
+int ipa_fold_round_run(Fe<F>* p, Fe<F>* b, Fe<F>* W, uint64_t half, uint64_t m0, const Fe<F>& u, hipStream_t st) {
+    if (half == 0) return ZK_OK;
+    if (W && (m0 == 0 || (m0 & (m0 - 1)) || half >= m0 || (half & (half - 1)))) return ZK_ERR_INVALID_ARG;
+    Fe<F> ui;
+    fe_inv(ui, u);
+    const uint64_t work = W && m0 > half ? m0 : half;
+    uint64_t blocks = (work + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ZK_LAUNCH((ipa_fold_round_kernel<F>), (unsigned)blocks, 256, 0, st, p, b, W, half, W ? m0 : 0, ui, u);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+template <class F>
 int vec_powers_run(DeviceCtx& dc, Fe<F>* out, uint64_t n, const Fe<F>& x, hipStream_t st) {
     if (n == 0) return ZK_OK;
     if (n > (1ull << 30)) return ZK_ERR_UNSUPPORTED;
@@ -346,6 +368,159 @@ int expr_eval_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const v
     if (blocks > 8192) blocks = 8192;
     ZK_LAUNCH((expr_eval_kernel<F>), (unsigned)blocks, EXPR_WG, 0, st, (const uint64_t*)base, n_ops, (const Fe<F>* const*)(base + pb), n_cols,
               (const Fe<F>*)(base + pb + cb), n_consts, log_n, rot_scale, out);
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+// ---- zk_expr_eval_lazy_device: the host side of expr_eval29_kernel ----
+// Walks the caller's program once with a (limb bound, value bound) pair per stack slot -- the discipline of zk_field29.h -- and
+// emits the kernel's program: the same operations plus, where a bound would be violated, a carry step (EXPR29_NORM) or a
+// contraction (EXPR29_REFRESH) on the top of the stack, and the bias table id of every subtraction / negation.
+//   loads            strict limbs, value < 2p (columns and constants are stored canonical; 2 leaves room for a lazily reduced producer)
+//   product a b      needs 9 eff(a) eff(b) + 9 2^58 + 2^36 < 2^64 with eff = max(limb bound, top limb of the value bound);
+//                    result strict, value < vb(a) vb(b) / ratio + 1, ratio = a lower bound of R' / p
+//   a + b            bounds add (limbs must stay below 2^32)
+//   a - b + BIAS     needs lb(b) <= k (2^29 - 1) and vb(b) + 2 <= M for the table (M p, k); limbs + (k + 1) 2^29, value + M
+//   a slot pushed to LDS is always normalised (<= 2^29 + 6) with value <= 32 p, so only the top of the stack ever needs fixing
+template <class F>
+int expr_compile29(const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, const void* const* cols, uint32_t n_consts, std::vector<uint64_t>& words,
+                   uint32_t& depth_out) {
+    using K = F29<F>;
+    const double W29 = (double)(1u << K::W), STRICT = W29 - 1, NP = W29 + 6, U32 = 4294967296.0, U64 = 18446744073709551616.0;
+    const double ptop1 = (double)K::P[K::L - 1] + 1;
+    const double ratio = W29 / ptop1;                          // R' / p >= 2^29 / (top limb of p + 1)
+    struct B {
+        double lb, vb;
+    };
+    auto eff = [&](const B& b) { return b.lb > b.vb * ptop1 ? b.lb : b.vb * ptop1; };
+    auto mul_ok = [&](const B& a, const B& b) { return 9.0 * eff(a) * eff(b) + 9.0 * W29 * W29 + 68719476736.0 < U64 * 0.999; };
+    std::vector<B> st;
+    words.clear();
+    auto emit = [&](uint32_t op, int rot, uint32_t arg) { words.push_back((uint64_t)op | ((uint64_t)(uint16_t)rot << 16) | ((uint64_t)arg << 32)); };
+    auto norm_top = [&]() {
+        emit(EXPR29_NORM, 0, 0);
+        st.back().lb = NP;
+    };
+    auto refresh_top = [&]() {
+        if (st.back().lb > NP) norm_top();
+        emit(EXPR29_REFRESH, 0, 0);
+        st.back().vb = st.back().vb / ratio + 1;
+        st.back().lb = STRICT;
+    };
+    const B ONE_B{STRICT, 1}, LOAD_B{STRICT, 2};
+    struct Bias {
+        double M, k;
+    };
+    const Bias biases[5] = {{4, 1}, {4, 2}, {8, 2}, {8, 3}, {16, 2}};     // ids = the kernel's fe29_sub_by_id
+    auto pick_bias = [&](const B& t) -> int {
+        int best = -1;
+        for (int id = 0; id < 5; id++)
+            if (t.lb <= biases[id].k * STRICT && t.vb + 2 <= biases[id].M) {
+                if (best < 0 || biases[id].M < biases[best].M || (biases[id].M == biases[best].M && biases[id].k < biases[best].k)) best = id;
+            }
+        return best;
+    };
+    auto bias_for_top = [&]() -> int {       // make the top of the stack subtractable, return its table
+        int id = pick_bias(st.back());
+        if (id < 0 && st.back().lb > NP) {
+            norm_top();
+            id = pick_bias(st.back());
+        }
+        if (id < 0) {
+            refresh_top();
+            id = pick_bias(st.back());
+        }
+        return id;
+    };
+    uint32_t depth = 0;
+    for (uint32_t k = 0; k < n_ops; k++) {
+        const zk_expr_op& o = prog[k];
+        if (o.op > 6) return ZK_ERR_INVALID_ARG;
+        if (o.op == 0 && (o.arg >= n_cols || !cols[o.arg])) return ZK_ERR_INVALID_ARG;
+        if ((o.op == 1 || o.op == 6) && o.arg >= n_consts) return ZK_ERR_INVALID_ARG;
+        if (o.op <= 1) {
+            if (!st.empty()) {                 // the current top goes to LDS: normalised, value <= 32 p
+                if (st.back().vb > 32) refresh_top();
+                if (st.back().lb > NP) norm_top();
+            }
+            emit(o.op, o.op == 0 ? o.rot : 0, o.arg);
+            st.push_back(LOAD_B);
+            if (st.size() > EXPR_STACK) return ZK_ERR_UNSUPPORTED;
+            if (st.size() - 1 > depth) depth = (uint32_t)st.size() - 1;
+        } else if (o.op == 5) {                // neg: 0 - t + BIAS
+            if (st.empty()) return ZK_ERR_INVALID_ARG;
+            const int id = bias_for_top();
+            if (id < 0) return ZK_ERR_UNSUPPORTED;
+            emit(5, 0, (uint32_t)id);
+            st.back() = B{(biases[id].k + 1) * W29, biases[id].M};
+        } else if (o.op == 6) {                // scale by a constant
+            if (st.empty()) return ZK_ERR_INVALID_ARG;
+            if (!mul_ok(st.back(), ONE_B) && st.back().lb > NP) norm_top();
+            if (!mul_ok(st.back(), ONE_B)) refresh_top();
+            if (!mul_ok(st.back(), ONE_B)) return ZK_ERR_UNSUPPORTED;
+            emit(6, 0, o.arg);
+            st.back() = B{STRICT, st.back().vb * 2 / ratio + 1};
+        } else {
+            if (st.size() < 2) return ZK_ERR_INVALID_ARG;
+            B x = st[st.size() - 2];
+            if (o.op == 2) {
+                if (x.lb + st.back().lb >= U32 * 0.99) norm_top();
+                if (x.vb + st.back().vb > 256) refresh_top();
+                emit(2, 0, 0);
+                x = B{x.lb + st.back().lb, x.vb + st.back().vb};
+            } else if (o.op == 3) {
+                const int id = bias_for_top();
+                if (id < 0) return ZK_ERR_UNSUPPORTED;
+                emit(3, 0, (uint32_t)id);
+                x = B{x.lb + (biases[id].k + 1) * W29, x.vb + biases[id].M};
+                if (x.lb >= U32 * 0.99) return ZK_ERR_UNSUPPORTED;   // (cannot happen: x was pushed normalised)
+            } else {
+                if (!mul_ok(x, st.back()) && st.back().lb > NP) norm_top();
+                if (!mul_ok(x, st.back())) refresh_top();
+                if (!mul_ok(x, st.back())) return ZK_ERR_UNSUPPORTED;
+                emit(4, 0, 0);
+                x = B{STRICT, x.vb * st.back().vb / ratio + 1};
+            }
+            st.pop_back();
+            st.back() = x;
+        }
+    }
+    if (st.size() != 1) return ZK_ERR_INVALID_ARG;
+    if (st.back().vb > 64) refresh_top();      // fe29_to_std: norm, product by R mod p, canonical (value < 20 p after the product)
+    if (words.size() > 2 * EXPR_MAX_OPS) return ZK_ERR_UNSUPPORTED;
+    depth_out = depth;
+    return ZK_OK;
+}
+
+// columns: x R' mod p (R' = 2^261), canonical words; constants: standard Montgomery on the host (converted here); out: standard
+template <class F>
+int expr_eval_lazy_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const Fe<F>* consts,
+                       uint32_t n_consts, uint32_t log_n, uint32_t rot_scale, Fe<F>* out, hipStream_t st) {
+    if (n_ops == 0 || n_ops > EXPR_MAX_OPS || n_cols > EXPR_MAX_COLS || n_consts > EXPR_MAX_CONSTS || log_n > 30) return ZK_ERR_INVALID_ARG;
+    std::vector<uint64_t> words;
+    uint32_t depth = 0;
+    ZK_TRY(expr_compile29<F>(prog, n_ops, n_cols, cols, n_consts, words, depth));
+    std::vector<Fe<F>> c29(n_consts ? n_consts : 1);
+    constexpr int SH = F29<F>::W * F29<F>::L - 32 * F::N;      // x R -> x R': times 2^5
+    for (uint32_t i = 0; i < n_consts; i++) {
+        c29[i] = consts[i];
+        for (int k = 0; k < SH; k++) fe_dbl(c29[i], c29[i]);
+    }
+    StreamScratch* ss = nullptr;
+    ZK_TRY(stream_scratch(dc, st, &ss));
+    const size_t pb = sizeof(uint64_t) * 2 * EXPR_MAX_OPS, cb = sizeof(void*) * EXPR_MAX_COLS, kb = sizeof(Fe<F>) * EXPR_MAX_CONSTS;
+    ZK_TRY(ws_get(ss->poly_tot, pb + cb + kb + 64));
+    unsigned char* base = (unsigned char*)ss->poly_tot.p;
+    HIP_TRY(hipMemcpyAsync(base, words.data(), sizeof(uint64_t) * words.size(), hipMemcpyHostToDevice, st));
+    if (n_cols) HIP_TRY(hipMemcpyAsync(base + pb, cols, sizeof(void*) * n_cols, hipMemcpyHostToDevice, st));
+    if (n_consts) HIP_TRY(hipMemcpyAsync(base + pb + cb, c29.data(), sizeof(Fe<F>) * n_consts, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // the sources are host temporaries
+    const uint64_t n = 1ull << log_n;
+    uint64_t blocks = (n + EXPR29_WG - 1) / EXPR29_WG;
+    if (blocks > 16384) blocks = 16384;
+    const size_t shmem = (size_t)(depth ? depth : 1) * F29<F>::L * EXPR29_WG * sizeof(uint32_t);
+    ZK_LAUNCH((expr_eval29_kernel<F>), (unsigned)blocks, EXPR29_WG, shmem, st, (const uint64_t*)base, (uint32_t)words.size(),
+              (const Fe<F>* const*)(base + pb), n_cols, (const Fe<F>*)(base + pb + cb), n_consts, log_n, rot_scale, depth, out);
     HIP_TRY(hipGetLastError());
     return ZK_OK;
 }

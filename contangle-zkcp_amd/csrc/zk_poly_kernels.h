@@ -14,6 +14,7 @@
 #pragma once
 #include "zk_rt.h"
 #include "zk_field.h"
+#include "zk_field29.h"
 #include "zk_ntt_kernels.h"
 
 namespace zk {
@@ -249,6 +250,54 @@ __global__ void __launch_bounds__(64) pow_ladder_kernel(Fe<F> x, Fe<F>* __restri
     for (int k = 0; k < 22; k++) {
         lad[32 + k] = w;
         fe_sqr(w, w);
+    }
+}
+
+// out[j] = sum_i s^(count - 1 - i) src_i[j], src_i = first + i * stride (stride in elements, may be negative): the whole Horner
+// fold of `count` resident polynomials in ONE pass -- every polynomial is read once and the result written once, where count - 1
+// muladd launches re-read and re-write the accumulator each time (3 x the traffic).  The multiopen argument folds every point
+// set's polynomials this way (powers of x_1), the vanishing argument the pieces of h (powers of x^n, last piece first).
+template <class F>
+__global__ void __launch_bounds__(256) vec_fold_many_kernel(Fe<F>* __restrict__ out, const Fe<F>* first, int64_t stride, uint32_t count, uint64_t n,
+                                                            Fe<F> s) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const Fe<F>* p = first + j;
+        Fe<F> acc = *p;
+        Fe<F> nxt = acc;
+        if (count > 1) nxt = p[stride];
+        for (uint32_t i = 1; i < count; i++) {
+            const Fe<F> y = nxt;
+            if (i + 1 < count) nxt = p[(int64_t)(i + 1) * stride];      // the next load overlaps the product
+            fe_mul(acc, acc, s);
+            fe_add(acc, acc, y);
+        }
+        out[j] = acc;
+    }
+}
+
+// one IPA round's three folds in one launch (poly/commitment/prover.rs: p'_i += u^-1 p'_(i+half), b_i += u b_(i+half), and for the
+// fold-free form the weights W[idx] *= u where idx has bit `half` set): the later rounds are bound by their dependent launches
+template <class F>
+__global__ void __launch_bounds__(256) ipa_fold_round_kernel(Fe<F>* __restrict__ p, Fe<F>* __restrict__ b, Fe<F>* __restrict__ W, uint64_t half,
+                                                             uint64_t m0, Fe<F> u_inv, Fe<F> u) {
+    const uint64_t work = half > m0 ? half : m0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < work; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (i < half) {
+            Fe<F> x = p[i], y = p[i + half];
+            fe_mul(y, y, u_inv);
+            fe_add(x, x, y);
+            p[i] = x;
+            x = b[i];
+            y = b[i + half];
+            fe_mul(y, y, u);
+            fe_add(x, x, y);
+            b[i] = x;
+        }
+        if (W != nullptr && i < m0 && (i & half)) {
+            Fe<F> x = W[i];
+            fe_mul(x, x, u);
+            W[i] = x;
+        }
     }
 }
 
@@ -548,6 +597,103 @@ __global__ void __launch_bounds__(EXPR_WG) expr_eval_kernel(const uint64_t* __re
             }
         }
         out[i] = tos;
+    }
+}
+
+// ---- the same evaluator on lazy 29-bit limbs (zk_field29.h): zk_expr_eval_lazy_device ----
+// The saturated form above spends ~290 instructions per product plus carry chains in every addition, and every operand goes
+// through LDS as 8 words.  Here the columns arrive as x R' mod p (R' = 2^261: the extended-coset transforms write that form when
+// asked, ZK_NTT_OUT_R29), are unpacked to 9 limbs on load, and products are the one-MAD-per-partial-product form (~205
+// instructions), additions 9 limb adds, subtractions 9 biased limb subtracts.  The bound discipline of zk_field29.h is
+// enforced by the HOST, which walks the program once (expr_compile29 in zk_poly.inl) tracking a limb bound and a value bound
+// per stack slot, picks the bias table of every subtraction / negation, and inserts the carry steps (EXPR29_NORM) and value
+// contractions (EXPR29_REFRESH: a product by R' mod p) that keep every product's operands inside fe29_mul's precondition.
+// The kernel only executes: it never decides anything about bounds.
+//   ops: 0 col  1 const  2 add  3 sub(arg = bias id)  4 mul  5 neg(arg = bias id)  6 scale(arg = const)  7 norm  8 refresh
+//   bias ids: 0 BIAS4K1  1 BIAS4K2  2 BIAS8K2  3 BIAS8K3  4 BIAS16K2
+// One wave per workgroup (the stacks are per lane: no barrier anywhere); the LDS stack is sized by the program's depth, so
+// shallow programs get more resident waves to hide the column loads behind.
+constexpr uint32_t EXPR29_WG = 64;
+enum : uint32_t { EXPR29_NORM = 7, EXPR29_REFRESH = 8 };
+
+template <class F>
+__device__ __forceinline__ void fe29_sub_by_id(Fe29<F>& r, const Fe29<F>& a, const Fe29<F>& b, uint32_t id) {
+    using K = F29<F>;
+    if (id == 0)
+        fe29_sub(r, a, b, K::BIAS4K1);
+    else if (id == 1)
+        fe29_sub(r, a, b, K::BIAS4K2);
+    else if (id == 2)
+        fe29_sub(r, a, b, K::BIAS8K2);
+    else if (id == 3)
+        fe29_sub(r, a, b, K::BIAS8K3);
+    else
+        fe29_sub(r, a, b, K::BIAS16K2);
+}
+
+template <class F>
+__global__ void __launch_bounds__(EXPR29_WG) expr_eval29_kernel(const uint64_t* __restrict__ prog, uint32_t n_ops, const Fe<F>* const* __restrict__ cols,
+                                                                uint32_t n_cols, const Fe<F>* __restrict__ consts, uint32_t n_consts, uint32_t log_n,
+                                                                uint32_t rot_scale, uint32_t depth, Fe<F>* __restrict__ out) {
+    ZK_DYN_SHARED(uint32_t, stack);   // depth slots: stack[(slot * L + limb) * EXPR29_WG + lane]
+    using K = F29<F>;
+    constexpr int L = K::L;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t n = 1ull << log_n, mask = n - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + lane; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t sp = 0;
+        Fe29<F> tos;
+        fe29_zero(tos);
+        for (uint32_t k = 0; k < n_ops; k++) {
+            const uint64_t w = prog[k];
+            const uint32_t op = (uint32_t)(w & 0xff), arg = (uint32_t)(w >> 32);
+            const int32_t rot = (int32_t)(int16_t)(uint16_t)(w >> 16);
+            if (op <= 1) {
+                if (sp > depth) break;
+                if (sp >= 1) {
+                    ZK_UNROLL
+                    for (int l = 0; l < L; l++) stack[((sp - 1) * L + l) * EXPR29_WG + lane] = tos.v[l];
+                }
+                Fe<F> raw;
+                if (op == 0) {
+                    const uint64_t j = (i + (uint64_t)((int64_t)rot * (int64_t)rot_scale)) & mask;
+                    raw = cols[arg < n_cols ? arg : 0][j];
+                } else {
+                    raw = consts[arg < n_consts ? arg : 0];
+                }
+                fe29_unpack(tos, raw);
+                sp++;
+            } else if (op == 5) {
+                Fe29<F> z;
+                fe29_zero(z);
+                fe29_sub_by_id<F>(tos, z, tos, arg);
+            } else if (op == 6) {
+                Fe29<F> c;
+                fe29_unpack(c, consts[arg < n_consts ? arg : 0]);
+                fe29_mul(tos, tos, c);
+            } else if (op == EXPR29_NORM) {
+                fe29_norm(tos, tos);
+            } else if (op == EXPR29_REFRESH) {
+                Fe29<F> one;
+                fe29_one(one);
+                fe29_mul(tos, tos, one);
+            } else {
+                if (sp < 2) break;
+                Fe29<F> x;
+                ZK_UNROLL
+                for (int l = 0; l < L; l++) x.v[l] = stack[((sp - 2) * L + l) * EXPR29_WG + lane];
+                if (op == 2)
+                    fe29_add(tos, x, tos);
+                else if (op == 3)
+                    fe29_sub_by_id<F>(tos, x, tos, arg);
+                else
+                    fe29_mul(tos, x, tos);
+                sp--;
+            }
+        }
+        Fe<F> r;
+        fe29_to_std(r, tos);      // x R' -> x R, canonical (the host left tos normalised enough for this product)
+        out[i] = r;
     }
 }
 

@@ -20,7 +20,8 @@ from . import (Bases, _check, _np64, _ptr, base_limbs, curve_id, field_id, field
 PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo2_permutation_product_device",
                   "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
                   "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device", "zk_ipa_collapse_range_device", "zk_ipa_round_device",
-                  "zk_poly_eval_device", "zk_poly_eval_batch_device", "zk_vec_muladd_device", "zk_vec_muladd_to_device", "zk_kate_division_device", "zk_vec_powers_device"]
+                  "zk_poly_eval_device", "zk_poly_eval_batch_device", "zk_vec_muladd_device", "zk_vec_muladd_to_device", "zk_kate_division_device", "zk_vec_powers_device", "zk_vec_fold_many_device",
+                  "zk_ipa_fold_round_device", "zk_expr_eval_lazy_device"]
 
 
 def best_multiexp(coeffs, bases):
@@ -112,7 +113,7 @@ class EvaluationDomain:
             raise AssertionError("assertion failed: a.values.len() == 1 << self.k")
         return ntt(self.field, a, self.omega, stream=stream, device=True)
 
-    def coeff_to_extended(self, a_ext, stream=0, coeffs=None):
+    def coeff_to_extended(self, a_ext, stream=0, coeffs=None, lazy_out=False):
         """`a_ext`: buffer of extended_len() whose first n entries are the coefficients (the rest is treated as the zeros
         upstream's `resize` appends): distribute_powers_zeta(into_coset) ; best_fft(extended_omega).  coeffs: take the n
         coefficients from that buffer instead (it is left untouched: the openings evaluate it later)"""
@@ -121,9 +122,10 @@ class EvaluationDomain:
         if coeffs is not None:
             if int(coeffs.shape[0]) != self.n:
                 raise AssertionError("assertion failed: a.len() == 1 << self.k")
-            return ntt(self.field, a_ext, self.extended_omega, stream=stream, coset_pre=self.g_coset, in_log=self.k, src=coeffs)
+            return ntt(self.field, a_ext, self.extended_omega, stream=stream, coset_pre=self.g_coset, in_log=self.k, src=coeffs,
+                       scale_by_n_inv=2 if lazy_out else 0)
         return ntt(self.field, a_ext, self.extended_omega, stream=stream, coset_pre=self.g_coset,
-                   in_log=self.k if self.extended_k > self.k else None, device=True)
+                   in_log=self.k if self.extended_k > self.k else None, device=True, scale_by_n_inv=2 if lazy_out else 0)
 
     def extended_to_coeff(self, a_ext, stream=0):
         """best_fft(extended_omega_inv) ; times extended_ifft_divisor ; distribute_powers_zeta(out of the coset).  Upstream
@@ -160,13 +162,14 @@ class EvaluationDomain:
             self._parts[key] = (_mont_limbs(g, p), _mont_limbs(pow(wi, parts, p), p))
         return self._parts[key]
 
-    def coeff_to_extended_part(self, coeffs, out, part, parts, stream=0):
-        """out[i] = the polynomial `coeffs` (n coefficients, untouched) at ZETA extended_omega^(i parts + part), i < extended_len / parts"""
+    def coeff_to_extended_part(self, coeffs, out, part, parts, stream=0, lazy_out=False):
+        """out[i] = the polynomial `coeffs` (n coefficients, untouched) at ZETA extended_omega^(i parts + part), i < extended_len / parts.
+        lazy_out: in the lazy-limb radix (x R' mod p) for evaluate_expression(lazy=True)"""
         self._part_check(part, parts)
         if int(coeffs.shape[0]) != self.n or int(out.shape[0]) != self.part_len(parts):
             raise AssertionError("assertion failed: coeffs.len() == n && out.len() == extended_len / parts")
         g, w = self._part_constants(part, parts)
-        return ntt(self.field, out, w, stream=stream, coset_pre=g, in_log=self.k, src=coeffs)
+        return ntt(self.field, out, w, stream=stream, coset_pre=g, in_log=self.k, src=coeffs, scale_by_n_inv=2 if lazy_out else 0)
 
     def divide_by_vanishing_poly_part(self, a_part, part, parts, stream=0):
         """a[i] *= t_evaluations[(i parts + part) mod 2^(extended_k - k)]"""
@@ -215,7 +218,10 @@ def _plib():
     lib.zk_poly_eval_batch_device.argtypes = [i32, vp, u64, ctypes.c_uint32, u64, vp, vp, vp]
     lib.zk_kate_division_device.argtypes = [i32, vp, vp, u64, vp, vp]
     lib.zk_vec_powers_device.argtypes = [i32, vp, u64, vp, vp]
+    lib.zk_vec_fold_many_device.argtypes = [i32, vp, vp, ctypes.c_int64, u32, u64, vp, vp]
+    lib.zk_ipa_fold_round_device.argtypes = [i32, vp, vp, vp, u64, u64, vp, vp]
     lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
+    lib.zk_expr_eval_lazy_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     return lib
 
 
@@ -298,6 +304,24 @@ def eval_polynomials(field, d_polys, x, stream=0):
     return out
 
 
+def vec_fold_many(field, out, polys, s, stream=0, reverse=False):
+    """out[j] = sum_i s^(count - 1 - i) polys[i][j] (Horner over the rows of `polys` [count, n, 4], one pass); reverse: walk the rows
+    from the last to the first (h(X) = sum_i (x^n)^i h_i: the last piece is the leading one)"""
+    ss = _np64(s)
+    count, n = int(polys.shape[0]), int(polys.shape[1])
+    first = polys[count - 1] if reverse else polys[0]
+    _check(_plib().zk_vec_fold_many_device(field_id(field), _ptr(out), _ptr(first), -n if reverse else n, count, n, _ptr(ss), ctypes.c_void_p(stream)),
+           "zk_vec_fold_many_device")
+    return out
+
+
+def ipa_fold_round(field, p, b, half, u, w=None, m0=0, stream=0):
+    """the three folds of one argument round in one launch (w: the fold-free form's weight vector over m0 generators)"""
+    uu = _np64(u)
+    _check(_plib().zk_ipa_fold_round_device(field_id(field), _ptr(p), _ptr(b), _ptr(w) if w is not None else None, half, m0, _ptr(uu),
+                                            ctypes.c_void_p(stream)), "zk_ipa_fold_round_device")
+
+
 def vec_powers(field, out, x, stream=0):
     """out[i] = x^i (the vector b of the inner-product argument: powers of x_3)"""
     xx = _np64(x)
@@ -329,17 +353,27 @@ def ipa_fold_bases(curve, g, half, u, stream=0):
     return g
 
 
-def evaluate_expression(field, program, columns, consts, log_n_ext, rot_scale, out, stream=0):
-    """program: list of ("col", column, rotation) / ("const", i) / ("add",) / ("sub",) / ("mul",) / ("neg",) / ("scale", i)"""
+def evaluate_expression(field, program, columns, consts, log_n_ext, rot_scale, out, stream=0, lazy=False):
+    """program: list of ("col", column, rotation) / ("const", i) / ("add",) / ("sub",) / ("mul",) / ("neg",) / ("scale", i).
+    lazy: the columns hold x R' mod p (coeff_to_extended(..., lazy_out=True) / to_lazy_form) and the evaluation runs on lazy
+    29-bit limbs; constants and the output stay in the usual Montgomery form"""
     ops = (ExprOp * len(program))()
     for k, o in enumerate(program):
         ops[k].op = EXPR_CODES[o[0]]
         ops[k].rot = o[2] if o[0] == "col" else 0
         ops[k].arg = o[1] if len(o) > 1 else 0
     cs = _np64(consts).reshape(-1, 4) if len(consts) else np.zeros((1, 4), dtype=np.uint64)
-    _check(_plib().zk_expr_eval_device(field_id(field), ops, len(program), _ptr_array(columns), len(columns), _ptr(cs), len(consts), log_n_ext,
-                                       rot_scale, _ptr(out), ctypes.c_void_p(stream)), "zk_expr_eval_device")
+    fn = _plib().zk_expr_eval_lazy_device if lazy else _plib().zk_expr_eval_device
+    _check(fn(field_id(field), ops, len(program), _ptr_array(columns), len(columns), _ptr(cs), len(consts), log_n_ext,
+              rot_scale, _ptr(out), ctypes.c_void_p(stream)), "zk_expr_eval_lazy_device" if lazy else "zk_expr_eval_device")
     return out
+
+
+def to_lazy_form(field, a, stream=0):
+    """x R -> x R' (R' = 2^261 for the 256-bit fields: times 2^5) in place: key material (fixed columns on the extended coset) for
+    evaluate_expression(lazy=True)"""
+    p = field_modulus(field)
+    return vec_op(field, "scale", a, scalar=_mont_limbs(32, p), stream=stream)
 
 
 class IpaProver:
@@ -448,11 +482,10 @@ class IpaProverVirtual:
 
     def fold(self, u):
         half = self.n // 2
-        vec_fold(self.field, self.p, half, field_inverse(self.field, u), stream=self.stream)
-        vec_fold(self.field, self.b, half, u, stream=self.stream)
-        uu = _np64(u)
-        _check(_plib().zk_ipa_update_weights_device(self.field, _ptr(self.W), self.m0, half, _ptr(uu), ctypes.c_void_p(self.stream)),
-               "zk_ipa_update_weights_device")
+        if half < self.m0:
+            ipa_fold_round(self.field, self.p, self.b, half, u, w=self.W, m0=self.m0, stream=self.stream)
+        else:      # (a single generator left over: nothing to weight)
+            ipa_fold_round(self.field, self.p, self.b, half, u, stream=self.stream)
         self.n = half
 
     def collapse(self, sharded=False):

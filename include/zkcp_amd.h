@@ -195,7 +195,10 @@ int zk_msm_batch_device(zk_curve_t c, uint64_t bases_handle, const void *scalars
 /* ---- NTT: in-place radix-2 DFT of size 2^log_n, natural order in and out ----
  * a[k] <- sum_j a[j] * omega^(jk); the caller passes omega (halo2 best_fft semantics: omega or
  * omega^-1, no implicit scaling).  scale_by_n_inv = 1 additionally multiplies by (2^log_n)^-1
- * (ark-poly ifft_in_place semantics when omega = group_gen_inv). */
+ * (ark-poly ifft_in_place semantics when omega = group_gen_inv).  On the device entry points the argument is a bit set:
+ * bit 0 = that scaling; ZK_NTT_OUT_R29 = write the results as x R' mod p, R' = 2^261 (the lazy-limb radix), for a
+ * consumer that computes on lazy limbs (zk_expr_eval_lazy_device) -- one constant changes in the last pass, no extra work. */
+#define ZK_NTT_OUT_R29 2
 int zk_ntt(zk_field_t f, void *a_mont_host, uint32_t log_n, const void *omega_mont_host, int scale_by_n_inv);
 int zk_ntt_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *omega_mont_host,
                   int scale_by_n_inv, void *hip_stream);

@@ -140,6 +140,16 @@ int zk_poly_eval_device(zk_field_t f, const void *coeffs_dev, uint64_t n, const 
 /* ... `count` polynomials of n coefficients (polynomial q at element offset q * stride_elems) at the same x: one launch, one copy */
 int zk_poly_eval_batch_device(zk_field_t f, const void *coeffs_dev, uint64_t n, uint32_t count, uint64_t stride_elems, const void *x_mont_host,
                               void *out_mont_host, void *hip_stream);
+/* out[j] = sum_{i < count} s^(count - 1 - i) src_i[j] with src_i = first_dev + i * stride_elems (stride may be negative: walk the
+ * polynomials backwards): the Horner fold of `count` resident polynomials in one pass, each read once (the x_1 fold of a point set
+ * in poly/multiopen/prover.rs; h(X) = sum_i x^(n i) h_i in plonk/vanishing/prover.rs with first = the LAST piece, stride = -n).
+ * out_dev may be one of the sources or disjoint from all of them. */
+int zk_vec_fold_many_device(zk_field_t f, void *out_dev, const void *first_dev, int64_t stride_elems, uint32_t count, uint64_t n,
+                            const void *s_mont_host, void *hip_stream);
+/* one round's three folds of the inner-product argument in one launch: p'[i] += u^-1 p'[i + half], b[i] += u b[i + half] for i < half,
+ * and (w_dev != NULL, the fold-free form) W[idx] *= u where idx < m0 has bit `half` set.  u != 0. */
+int zk_ipa_fold_round_device(zk_field_t f, void *p_dev, void *b_dev, void *w_dev, uint64_t half, uint64_t m0, const void *u_mont_host,
+                             void *hip_stream);
 /* out[i] = x^i, i < n: the vector b of poly/commitment/prover.rs create_proof (powers of x_3), built from per-call power tables of x */
 int zk_vec_powers_device(zk_field_t f, void *out_dev, uint64_t n, const void *x_mont_host, void *hip_stream);
 /* arithmetic.rs kate_division(a, x): the quotient of (a(X) - a(x)) / (X - x) as n coefficients (upstream returns n - 1 and
@@ -198,6 +208,15 @@ typedef struct {
 int zk_expr_eval_device(zk_field_t f, const zk_expr_op *program_host, uint32_t n_ops, const void *const *columns_dev, uint32_t n_columns,
                         const void *consts_mont_host, uint32_t n_consts, uint32_t log_n_ext, uint32_t rot_scale, void *out_dev,
                         void *hip_stream);
+
+/* The same evaluation on lazy 29-bit limbs (one MAD per partial product, carry-free additions): the columns must hold x R' mod p
+ * with R' = 2^261 -- what the NTT entry points write when their scale argument has ZK_NTT_OUT_R29 set (zkcp_amd.h), or
+ * zk_vec_op_device(scale) by 2^5 for key material -- as canonical 256-bit words.  Constants come in the usual Montgomery form and
+ * the OUTPUT is in the usual form too.  The host walks the program once to place the carry steps and pick the subtraction
+ * biases (the bound discipline of csrc/zk_field29.h); same validation and limits as zk_expr_eval_device. */
+int zk_expr_eval_lazy_device(zk_field_t f, const zk_expr_op *program_host, uint32_t n_ops, const void *const *columns_r29_dev, uint32_t n_columns,
+                             const void *consts_mont_host, uint32_t n_consts, uint32_t log_n_ext, uint32_t rot_scale, void *out_dev,
+                             void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -239,6 +239,10 @@ extern "C" {
     pub fn zk_vec_muladd_device(f: c_int, a_dev: *mut c_void, b_dev: *const c_void, n: u64, s_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_vec_muladd_to_device(f: c_int, out_dev: *mut c_void, a_dev: *const c_void, b_dev: *const c_void, n: u64, s_mont_host: *const c_void,
                                    hip_stream: *mut c_void) -> c_int;
+    pub fn zk_vec_fold_many_device(f: c_int, out_dev: *mut c_void, first_dev: *const c_void, stride_elems: i64, count: u32, n: u64,
+                                   s_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn zk_ipa_fold_round_device(f: c_int, p_dev: *mut c_void, b_dev: *mut c_void, w_dev: *mut c_void, half: u64, m0: u64,
+                                    u_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_vec_powers_device(f: c_int, out_dev: *mut c_void, n: u64, x_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_kate_division_device(f: c_int, a_dev: *const c_void, q_dev: *mut c_void, n: u64, x_mont_host: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn zk_poly_eval_batch_device(f: c_int, coeffs_dev: *const c_void, n: u64, count: u32, stride_elems: u64, x_mont_host: *const c_void,
@@ -255,6 +259,9 @@ extern "C" {
     pub fn zk_ipa_collapse_device(c: c_int, bases_handle: u64, w_dev: *const c_void, m0: u64, cur: u64, g_out_affine_dev: *mut c_void,
                                   hip_stream: *mut c_void) -> c_int;
     pub fn zk_expr_eval_device(f: c_int, program_host: *const zk_expr_op, n_ops: u32, columns_dev: *const *const c_void, n_columns: u32,
+                               consts_mont_host: *const c_void, n_consts: u32, log_n_ext: u32, rot_scale: u32, out_dev: *mut c_void,
+                               hip_stream: *mut c_void) -> c_int;
+    pub fn zk_expr_eval_lazy_device(f: c_int, program_host: *const zk_expr_op, n_ops: u32, columns_dev: *const *const c_void, n_columns: u32,
                                consts_mont_host: *const c_void, n_consts: u32, log_n_ext: u32, rot_scale: u32, out_dev: *mut c_void,
                                hip_stream: *mut c_void) -> c_int;
 }

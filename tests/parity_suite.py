@@ -602,8 +602,11 @@ def check_halo2_domain(zk, name, k, j=9):
     while parts <= (1 << (ek - k)):
         for part in range(parts):
             d_co, d_pt = to_device(zk, coeffs), to_device(zk, np.full((ne // parts, 4), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64))
+            dom.coeff_to_extended_part(d_co, d_pt, part, parts, lazy_out=True)      # ZK_NTT_OUT_R29: the same values times 2^5
+            lz = to_host(zk, d_pt).copy()
             dom.coeff_to_extended_part(d_co, d_pt, part, parts)
             assert (to_host(zk, d_pt) == exp_ext[part::parts]).all(), (name, k, part, parts, "coeff_to_extended_part")
+            assert (lz == to_host(zk, zk.halo2.to_lazy_form(name, to_device(zk, exp_ext[part::parts])))).all(), (name, k, part, parts, "lazy_out")
             dom.divide_by_vanishing_poly_part(d_pt, part, parts)
             assert (to_host(zk, d_pt) == exp_div_all[part::parts]).all(), (name, k, part, parts, "divide_by_vanishing_poly_part")
         assert dom.rot_scale_part(parts) * parts == 1 << (ek - k)
@@ -782,6 +785,19 @@ def check_eval_polynomial(zk, name, sizes=(1, 2, 15, 16, 17, 1000, 4099), seed=7
     d_a, d_b, d_o = to_device(zk, _monts(name, a)), to_device(zk, _monts(name, b)), to_device(zk, np.zeros((n, 4), dtype=np.uint64))
     zk.halo2.vec_muladd(name, d_a, d_b, _monts(name, [sc])[0], out=d_o)
     assert (to_host(zk, d_o) == got).all() and (to_host(zk, d_a) == _monts(name, a)).all(), (name, "muladd into a third buffer")
+    # the whole Horner fold of several polynomials in one pass, forwards (a point set with x_1) and backwards (h's pieces with x^n)
+    n, count = 700, 6
+    polys = [[rng.below(p) for _ in range(n)] for _ in range(count)]
+    d_polys = to_device(zk, np.stack([_monts(name, c) for c in polys]))
+    for reverse in (False, True):
+        order = polys[::-1] if reverse else polys
+        exp = list(order[0])
+        for q in order[1:]:
+            exp = [(e_ * sc + v_) % p for e_, v_ in zip(exp, q)]
+        got = to_host(zk, zk.halo2.vec_fold_many(name, to_device(zk, np.zeros((n, 4), dtype=np.uint64)), d_polys, _monts(name, [sc])[0], reverse=reverse))
+        assert (got == _monts(name, exp)).all(), (name, "fold_many", reverse)
+    one = zk.halo2.vec_fold_many(name, to_device(zk, np.zeros((n, 4), dtype=np.uint64)), d_polys[:1], _monts(name, [sc])[0])
+    assert (to_host(zk, one) == _monts(name, polys[0])).all()
     # several polynomials at one point in one launch
     n, count = 300, 5
     polys = [[rng.below(p) for _ in range(n)] for _ in range(count)]
@@ -980,6 +996,24 @@ def check_expression(zk, name, k, ext=2, seed=21):
     out = to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
     zk.halo2.evaluate_expression(name, prog, [to_device(zk, c) for c in cols], _monts(name, consts), ek, scale, out)
     assert (to_host(zk, out) == _monts(name, exp)).all(), (name, k)
+    # the lazy-limb evaluator: columns in the R' = 2^261 radix (times 2^5), constants and output in the usual form
+    lazy_cols = [zk.halo2.to_lazy_form(name, to_device(zk, c)) for c in cols]
+    out2 = to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
+    zk.halo2.evaluate_expression(name, prog, lazy_cols, _monts(name, consts), ek, scale, out2, lazy=True)
+    assert (to_host(zk, out2) == _monts(name, exp)).all(), (name, k, "lazy limbs")
+    # adversarial bounds for the host's bound walk: long chains of additions / subtractions / negations before a product, at the
+    # extreme stored values (all columns p - 1, or 0)
+    top = np.tile(orc.int_to_limbs(p - 1, 4), (ne, 1))       # as stored words: x R' = p - 1
+    zero = np.zeros((ne, 4), dtype=np.uint64)
+    chain = [a] + [a, ("add",)] * 40 + [b] + [b, ("sub",)] * 9 + [("neg",), ("mul",), c, ("neg",), ("neg",), ("sub",)] + [c, ("add",)] * 70 + [qm, ("mul",), ("neg",)]
+    for fill in (top, zero):
+        ccols = [to_device(zk, fill) for _ in range(5)]
+        xval = (p - 1 if fill is top else 0) * pow(1 << 261, -1, p) % p      # the value x behind the stored word x R'
+        icol = [[xval] * ne for _ in range(5)]
+        e0 = h2.eval_program(name, chain, icol, consts, ne, scale, 0)
+        out3 = to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
+        zk.halo2.evaluate_expression(name, chain, ccols, _monts(name, consts), ek, scale, out3, lazy=True)
+        assert (to_host(zk, out3) == _monts(name, [e0])[0]).all(), (name, k, "lazy limbs at the bounds")
     for bad in ([("add",)], [a, b], [("col", 9, 0)], [("const", 7)], [a] * 9 + [("add",)] * 8):   # malformed programs are refused on the host
         try:
             zk.halo2.evaluate_expression(name, bad, [to_device(zk, c) for c in cols], _monts(name, consts), ek, scale, out)
@@ -1016,6 +1050,12 @@ def check_expression_at_size(zk, name, k, ext, n_adv=13, n_fix=8, n_inst=3, samp
     out = to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
     zk.halo2.evaluate_expression(name, prog, d_cols, consts, ek, scale, out)
     got = to_host(zk, out)
+    # ... and the lazy-limb evaluator on the same columns in the R' radix
+    for d in d_cols:
+        zk.halo2.to_lazy_form(name, d)
+    out.zero_() if hasattr(out, "zero_") else out.fill(0)
+    zk.halo2.evaluate_expression(name, prog, d_cols, consts, ek, scale, out, lazy=True)
+    assert (to_host(zk, out) == got).all(), (name, k, ext, "lazy limbs differ from the saturated evaluator")
     rng = pyref.Rng(seed)
     rows = sorted({0, 1, scale - 1, scale, scale + 1, ne - 1, ne - 2, ne - scale, ne - scale - 1, ne // 2, ne // 2 - 1}
                   | {rng.below(ne) for _ in range(samples)})

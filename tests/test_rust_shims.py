@@ -37,6 +37,67 @@ def test_extern_block_matches_headers():
         assert c[name] == r[name], (name, c[name], r[name])
 
 
+C_TO_RUST = [   # C parameter type (normalised) -> the Rust FFI type that has the same size, signedness and pointer constness
+    (r"const void \*const \*", "*const *const c_void"), (r"const void \*", "*const c_void"), (r"void \*", "*mut c_void"),
+    (r"const uint8_t \*", "*const u8"), (r"uint8_t \*", "*mut u8"), (r"const uint64_t \*", "*const u64"), (r"uint64_t \*", "*mut u64"),
+    (r"const uint32_t \*", "*const u32"), (r"const int \*", "*const c_int"), (r"char \*", "*mut c_char"),
+    (r"const (zk_[a-z0-9_]+) \*", "*const \\1"), (r"(zk_[a-z0-9_]+) \*", "*mut \\1"),
+    (r"uint64_t", "u64"), (r"uint32_t", "u32"), (r"int64_t", "i64"), (r"int", "c_int"),
+    (r"zk_curve_t|zk_field_t|zk_pairing_t", "c_int"),
+]
+
+
+def _c_params():
+    out = {}
+    for h in ("zkcp_amd.h", "zkcp_amd_prover.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b(?:int|const char \*)\s*(zk_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+            args = " ".join(m.group(2).split())
+            params = [] if args in ("void", "") else [a.strip() for a in args.split(",")]
+            types = []
+            for a in params:
+                t = re.sub(r"\b[a-zA-Z_][a-zA-Z0-9_]*$", "", a).strip()      # drop the parameter name
+                t = re.sub(r"\s*\*\s*", " *", t).replace("* *", "**").strip()
+                types.append(re.sub(r"\s+", " ", t))
+            out[m.group(1)] = types
+    return out
+
+
+def _rust_params():
+    src = open(os.path.join(ROOT, "rust", "zkcp-amd-sys", "src", "lib.rs")).read()
+    block = src[src.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    out = {}
+    for m in re.finditer(r"pub fn (zk_[a-z0-9_]+)\s*\(([^;]*?)\)\s*(?:->\s*[^;]+)?;", block, flags=re.S):
+        args = " ".join(m.group(2).split())
+        out[m.group(1)] = [a.split(":", 1)[1].strip() for a in args.split(",") if ":" in a]
+    return out
+
+
+def _expected_rust(ctype):
+    t = ctype.replace("const void *const*", "const void *const *").replace(" **", " * *")
+    for pat, rust in C_TO_RUST:
+        m = re.fullmatch(pat, t)
+        if m:
+            return m.expand(rust) if "\\1" in rust else rust
+    raise AssertionError("no Rust mapping for C type %r" % ctype)
+
+
+def test_extern_block_parameter_types_match():
+    """every parameter of every bound function: pointer vs integer, integer width, pointee type and constness -- a function body
+    swap or a u32 / u64 mix-up in rust/zkcp-amd-sys/src/lib.rs fails here (counts alone would not notice)"""
+    c, r = _c_params(), _rust_params()
+    checked = 0
+    for name, ctypes_ in c.items():
+        assert name in r, name
+        assert len(ctypes_) == len(r[name]), (name, ctypes_, r[name])
+        for i, (ct, rt) in enumerate(zip(ctypes_, r[name])):
+            assert _expected_rust(ct) == rt, (name, i, ct, rt, _expected_rust(ct))
+            checked += 1
+    assert checked > 400
+
+
 def test_repr_c_structs_match():
     hdr = open(os.path.join(ROOT, "include", "zkcp_amd.h")).read() + open(os.path.join(ROOT, "include", "zkcp_amd_prover.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
