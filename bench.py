@@ -767,7 +767,8 @@ def bench_groth16(e):
         if e.world > 1:
             torch.cuda.synchronize()
             e.dist.broadcast(d_abc[0], src=0)
-        jobs = ((h_query, d_abc[0][:m - 1], True), (a_query, z, False), (b_g1_query, z, False), (l_query, z_aux, False), (b_g2_query, z, False))
+        # (the G2 MSM first: its host tail -- Horner on Fq2 host limbs, the longest of the five -- then runs beside the G1 MSMs' device work)
+        jobs = ((b_g2_query, z, False), (h_query, d_abc[0][:m - 1], True), (a_query, z, False), (b_g1_query, z, False), (l_query, z_aux, False))
         result["pts"] = e.zkdist.msm_many_sharded(jobs, window_bits=a.window_bits, stream=e.st)
         if timed_ and e.rank == 0:
             torch.cuda.synchronize()

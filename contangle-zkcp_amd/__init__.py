@@ -48,13 +48,14 @@ class MsmOpts(ctypes.Structure):
     _fields_ = [("window_bits", ctypes.c_int), ("window_begin", ctypes.c_int), ("window_end", ctypes.c_int),
                 ("limb_bits", ctypes.c_int), ("split_log_plus1", ctypes.c_int), ("slice_len", ctypes.c_int),
                 ("big_threshold", ctypes.c_int), ("waves_per_simd", ctypes.c_int), ("flags", ctypes.c_int),
-                ("base_offset", ctypes.c_int), ("reserved", ctypes.c_int * 2)]
+                ("base_offset", ctypes.c_int), ("window_group", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
 MSM_FLAG_NO_HOT_HELP = 1
 MSM_FLAG_SLICE_REDUCE = 2
 MSM_FLAG_PRECOMPUTED = 4
 MSM_FLAG_DEVICE_PARTIALS = 8
+MSM_FLAG_OWN_STREAM = 16
 
 
 class NttOpts(ctypes.Structure):
@@ -292,7 +293,7 @@ class Bases:
 
 
 def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len=0, big_threshold=0, waves_per_simd=0,
-             no_hot_help=False, base_offset=0, slice_reduce=False, precomputed=False, device_partials=False):
+             no_hot_help=False, base_offset=0, slice_reduce=False, precomputed=False, device_partials=False, own_stream=False, window_group=0):
     o = MsmOpts()
     o.window_bits = window_bits
     if windows is not None:
@@ -303,8 +304,9 @@ def msm_opts(window_bits=0, windows=None, limb_bits=0, split_log=None, slice_len
     o.big_threshold = big_threshold
     o.waves_per_simd = waves_per_simd
     o.flags = ((MSM_FLAG_NO_HOT_HELP if no_hot_help else 0) | (MSM_FLAG_SLICE_REDUCE if slice_reduce else 0)
-               | (MSM_FLAG_PRECOMPUTED if precomputed else 0) | (MSM_FLAG_DEVICE_PARTIALS if device_partials else 0))
+               | (MSM_FLAG_PRECOMPUTED if precomputed else 0) | (MSM_FLAG_DEVICE_PARTIALS if device_partials else 0) | (MSM_FLAG_OWN_STREAM if own_stream else 0))
     o.base_offset = base_offset
+    o.window_group = window_group
     return o
 
 

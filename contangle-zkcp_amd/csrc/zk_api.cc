@@ -108,6 +108,7 @@ MsmTuning tuning_from(const zk_msm_opts* o) {
     t.precomputed = (o->flags & ZK_MSM_FLAG_PRECOMPUTED) != 0;
     t.device_partials = (o->flags & ZK_MSM_FLAG_DEVICE_PARTIALS) != 0;
     t.base_offset = o->base_offset > 0 ? (uint64_t)o->base_offset : 0;
+    t.window_group = o->window_group > 0 ? o->window_group : 0;
     return t;
 }
 
@@ -122,11 +123,16 @@ void free_job(MsmJob& j) {
         for (auto& e : j.ev) hipEventDestroy(e);
         j.have_events = false;
     }
+    for (auto& e : j.acc_ev) hipEventDestroy(e);
+    j.acc_ev.clear();
     j.busy = false;
 }
 
+void stop_worker(DeviceCtx& dc);
 void free_device(DeviceCtx& dc) {
+    stop_worker(dc);
     hipSetDevice(dc.device);
+    ws_free(dc.batch_in);
     hipDeviceSynchronize();
     for (auto& kv : dc.tw) hipFree(kv.second.dev);
     dc.tw.clear();
@@ -151,6 +157,11 @@ void free_device(DeviceCtx& dc) {
     dc.ntt_ev_pool.clear();
     dc.ntt_ev_used = 0;
     for (auto& s : dc.side)
+        if (s) {
+            hipStreamDestroy(s);
+            s = nullptr;
+        }
+    for (auto& s : dc.submit_streams)
         if (s) {
             hipStreamDestroy(s);
             s = nullptr;
@@ -185,6 +196,7 @@ DeviceCtx& device_of(const void* p) {
 int ensure_lib_streams(DeviceCtx& dc) {
     if (!dc.side[0]) {
         for (auto& s : dc.side) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        for (auto& s : dc.submit_streams) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&dc.own, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&dc.fork_ev, hipEventDisableTiming));
         for (auto& e : dc.join_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -290,29 +302,72 @@ int find_bases(uint64_t handle, zk_curve_t c, uint64_t n, const BasesEntry** out
     return ZK_OK;
 }
 
+// ---- persistent per-device workers (multi-device processes)
+void worker_loop(DeviceCtx* dc) {
+    hipSetDevice(dc->device);
+    DeviceWorker& w = *dc->worker;
+    for (;;) {
+        std::packaged_task<int()> task;
+        {
+            std::unique_lock<std::mutex> lk(w.mu);
+            w.cv.wait(lk, [&] { return w.stop || !w.q.empty(); });
+            if (w.q.empty()) return;     // stop requested and nothing left
+            task = std::move(w.q.front());
+            w.q.pop_front();
+        }
+        task();
+    }
+}
+std::future<int> run_on_device(DeviceCtx& dc, std::function<int()> fn) {
+    std::packaged_task<int()> task(std::move(fn));
+    std::future<int> fut = task.get_future();
+    if (!dc.worker) {      // single-device process: inline
+        task();
+        return fut;
+    }
+    {
+        std::lock_guard<std::mutex> lk(dc.worker->mu);
+        dc.worker->q.push_back(std::move(task));
+    }
+    dc.worker->cv.notify_one();
+    return fut;
+}
+void stop_worker(DeviceCtx& dc) {
+    if (!dc.worker) return;
+    {
+        std::lock_guard<std::mutex> lk(dc.worker->mu);
+        dc.worker->stop = true;
+    }
+    dc.worker->cv.notify_one();
+    if (dc.worker->th.joinable()) dc.worker->th.join();
+    dc.worker.reset();
+}
+
+size_t jac_bytes(zk_curve_t c) {
+    size_t w = 0;
+    switch (c) {
+        case ZK_PALLAS: w = coord_words<Pallas>(); break;
+        case ZK_VESTA: w = coord_words<Vesta>(); break;
+        case ZK_BN254_G1: w = coord_words<Bn254G1>(); break;
+        case ZK_BLS12_381_G1: w = coord_words<Bls381G1>(); break;
+        case ZK_BN254_G2: w = coord_words<Bn254G2>(); break;
+        default: w = coord_words<Bls381G2>(); break;
+    }
+    return (size_t)3 * 4 * w;
+}
+
 // One MSM over all devices of the process: device d sums windows [W d / G, W (d + 1) / G) from its own resident copy of
 // the bases; the Jacobian partial sums are added on the host (EC addition is not an RCCL reduction; the partial is 96 -
 // 288 bytes and is already on the host after the job's tail).  `src` is where the scalars are: a host pointer (src_dc ==
 // nullptr; every device copies them over its own PCIe link) or a device pointer owned by src_dc (peers copy over xGMI).
+// The shares run on the devices' persistent workers; the calling thread takes device 0's.
 int msm_fanout(zk_curve_t c, const BasesEntry& be, const void* src, DeviceCtx* src_dc, hipStream_t src_stream, uint64_t n, int mont,
                const MsmTuning& tu_in, void* out) {
     const int G = (int)g.devs.size();
     int nwin = 0;
     CURVE_SWITCH(c, nwin = msm_windows<C>(msm_pick_c(n, tu_in.window_bits)));
-    const size_t pbytes = (size_t)3 * 4 * [&]() -> size_t {
-        size_t w = 0;
-        switch (c) {
-            case ZK_PALLAS: w = coord_words<Pallas>(); break;
-            case ZK_VESTA: w = coord_words<Vesta>(); break;
-            case ZK_BN254_G1: w = coord_words<Bn254G1>(); break;
-            case ZK_BLS12_381_G1: w = coord_words<Bls381G1>(); break;
-            case ZK_BN254_G2: w = coord_words<Bn254G2>(); break;
-            default: w = coord_words<Bls381G2>(); break;
-        }
-        return w;
-    }();
+    const size_t pbytes = jac_bytes(c);
     std::vector<std::vector<unsigned char>> parts(G, std::vector<unsigned char>(pbytes));
-    std::vector<int> status(G, ZK_OK);
     hipEvent_t ready = nullptr;
     if (src_dc) {   // peers must not read the scalars before the caller's stream has produced them
         hipSetDevice(src_dc->device);
@@ -321,13 +376,12 @@ int msm_fanout(zk_curve_t c, const BasesEntry& be, const void* src, DeviceCtx* s
         ready = src_dc->fork_ev;
         HIP_TRY(hipEventRecord(ready, src_stream));
     }
-    auto work = [&](int d) {
+    auto work = [&](int d) -> int {
         DeviceCtx& dc = *g.devs[d];
         MsmTuning tu = tu_in;
         tu.w0 = nwin * d / G;
         tu.w1 = nwin * (d + 1) / G;
         MsmJob* job = nullptr;
-        int st_ = ZK_OK;
         auto run = [&]() -> int {
             ZK_TRY(bind_device(dc));
             std::lock_guard<std::mutex> lk(dc.mu);
@@ -341,15 +395,18 @@ int msm_fanout(zk_curve_t c, const BasesEntry& be, const void* src, DeviceCtx* s
             HIP_TRY(hipStreamWaitEvent(dc.own, ready, 0));
             return submit_on(dc, c, be, src, SRC_PEER, src_dc->device, n, mont, tu, dc.own, &job);
         };
-        st_ = run();
+        int st_ = run();
         if (st_ == ZK_OK) st_ = collect_job(*job, parts[d].data());
-        status[d] = st_;
+        return st_;
     };
-    std::vector<std::thread> th;
-    for (int d = 1; d < G; d++) th.emplace_back(work, d);
-    work(0);
-    for (auto& t : th) t.join();
-    for (int d = 0; d < G; d++) ZK_TRY(status[d]);
+    std::vector<std::future<int>> fut;
+    for (int d = 1; d < G; d++) fut.push_back(run_on_device(*g.devs[d], [&, d] { return work(d); }));
+    int status = work(0);
+    for (auto& f : fut) {
+        const int s2 = f.get();
+        if (status == ZK_OK) status = s2;
+    }
+    ZK_TRY(status);
     memcpy(out, parts[0].data(), pbytes);
     for (int d = 1; d < G; d++) ZK_TRY(point_add_host(c, out, parts[d].data(), out));
     hipSetDevice(g.devs[0]->device);
@@ -404,6 +461,11 @@ int init_devices_locked(int n, const int* ids) {
 #endif
     hipSetDevice(ids[0]);
     g.devs = std::move(devs);
+    if (n > 1)
+        for (auto& dc : g.devs) {
+            dc->worker.reset(new DeviceWorker());
+            dc->worker->th = std::thread(worker_loop, dc.get());
+        }
     memset(&g.ntt_opts, 0, sizeof g.ntt_opts);
     memset(&g.totals, 0, sizeof g.totals);
     g.ntt_profile = false;
@@ -654,30 +716,109 @@ API int zk_msm_submit(zk_curve_t c, uint64_t handle, const void* d_scalars, uint
     const BasesEntry* be = nullptr;
     ZK_TRY(find_bases(handle, c, n, &be, opts));
     DeviceCtx& dc = device_of(d_scalars);
+    if (g.devs.size() > 1 && whole_msm(tuning_from(opts)) && n > 0) {
+        // one process, several GPUs: one job per device (its window share), enqueued here without waiting; the peers copy the
+        // scalars over xGMI into their job's own staging buffer behind an event on the caller's stream
+        const int G = (int)g.devs.size();
+        int nwin = 0;
+        const MsmTuning tu_in = tuning_from(opts);
+        CURVE_SWITCH(c, nwin = msm_windows<C>(msm_pick_c(n, tu_in.window_bits)));
+        hipEvent_t ready = nullptr;
+        {
+            ZK_TRY(bind_device(dc));
+            std::lock_guard<std::mutex> lk(dc.mu);
+            ZK_TRY(ensure_lib_streams(dc));
+            ready = dc.fork_ev;
+            HIP_TRY(hipEventRecord(ready, (hipStream_t)stream));
+        }
+        std::vector<MsmJob*> jobs;
+        int status = ZK_OK;
+        for (int d = 0; d < G && status == ZK_OK; d++) {
+            DeviceCtx& dd = *g.devs[d];
+            MsmTuning tu = tu_in;
+            tu.w0 = nwin * d / G;
+            tu.w1 = nwin * (d + 1) / G;
+            MsmJob* job = nullptr;
+            status = bind_device(dd);
+            if (status != ZK_OK) break;
+            std::lock_guard<std::mutex> lk(dd.mu);
+            if (tu.w0 == tu.w1) {
+                tu.w0 = tu.w1 = 0;
+                status = submit_on(dd, c, *be, nullptr, SRC_LOCAL, 0, 0, mont ? 1 : 0, tu, nullptr, &job);
+            } else if (&dd == &dc) {
+                status = submit_on(dd, c, *be, d_scalars, SRC_LOCAL, 0, n, mont ? 1 : 0, tu, (hipStream_t)stream, &job);
+            } else {
+                status = ensure_lib_streams(dd);
+                if (status == ZK_OK && hipStreamWaitEvent(dd.own, ready, 0) != hipSuccess) status = ZK_ERR_HIP;
+                if (status == ZK_OK) status = submit_on(dd, c, *be, d_scalars, SRC_PEER, dc.device, n, mont ? 1 : 0, tu, dd.own, &job);
+            }
+            if (status == ZK_OK) jobs.push_back(job);
+        }
+        hipSetDevice(g.devs[0]->device);
+        if (status != ZK_OK) {      // release what was taken
+            for (MsmJob* j : jobs) {
+                std::vector<unsigned char> sink(jac_bytes(c));
+                collect_job(*j, sink.data());
+            }
+            return status;
+        }
+        std::lock_guard<std::mutex> lk(g.mu);
+        const uint64_t t = g.next_ticket++;
+        for (MsmJob* j : jobs) j->ticket = t;
+        g.tickets[t] = jobs;
+        *ticket_out = t;
+        return ZK_OK;
+    }
     ZK_TRY(bind_device(dc));
     MsmJob* job = nullptr;
     {
         std::lock_guard<std::mutex> lk(dc.mu);
-        ZK_TRY(submit_on(dc, c, *be, d_scalars, SRC_LOCAL, 0, n, mont ? 1 : 0, tuning_from(opts), (hipStream_t)stream, &job));
+        hipStream_t run_on = (hipStream_t)stream;
+        if (opts && (opts->flags & ZK_MSM_FLAG_OWN_STREAM)) {
+            // the job runs on a library stream forked behind what `stream` holds now: the latency-bound phases of one MSM (the
+            // oversized-bucket path and the bucket reduction: dependent additions at one wave per SIMD on the G2 types) then
+            // run beside the next MSM's accumulate kernel instead of in front of it
+            ZK_TRY(ensure_lib_streams(dc));
+            HIP_TRY(hipEventRecord(dc.fork_ev, (hipStream_t)stream));
+            run_on = dc.submit_streams[dc.submit_rr++ % ZK_MAX_JOBS];     // as many streams as job slots: every MSM in flight has its own
+            HIP_TRY(hipStreamWaitEvent(run_on, dc.fork_ev, 0));
+        }
+        ZK_TRY(submit_on(dc, c, *be, d_scalars, SRC_LOCAL, 0, n, mont ? 1 : 0, tuning_from(opts), run_on, &job));
     }
     std::lock_guard<std::mutex> lk(g.mu);
     job->ticket = g.next_ticket++;
-    g.tickets[job->ticket] = job;
+    g.tickets[job->ticket] = {job};
     *ticket_out = job->ticket;
     return ZK_OK;
 }
 API int zk_msm_collect(uint64_t ticket, void* out) {
     if (!out) return ZK_ERR_INVALID_ARG;
-    MsmJob* job = nullptr;
+    std::vector<MsmJob*> jobs;
     {
         std::lock_guard<std::mutex> lk(g.mu);
         ZK_TRY(require_init());
         auto it = g.tickets.find(ticket);
         if (it == g.tickets.end()) return ZK_ERR_BAD_HANDLE;
-        job = it->second;
+        jobs = it->second;
         g.tickets.erase(it);
     }
-    return collect_job(*job, out);
+    if (jobs.size() == 1) return collect_job(*jobs[0], out);
+    // a fanned-out submission: one window share per device; the tails run on the devices' workers, the partials are added here
+    const zk_curve_t c = (zk_curve_t)jobs[0]->curve;
+    const size_t pbytes = jac_bytes(c);
+    std::vector<std::vector<unsigned char>> parts(jobs.size(), std::vector<unsigned char>(pbytes));
+    std::vector<std::future<int>> fut;
+    for (size_t d = 1; d < jobs.size(); d++) fut.push_back(run_on_device(*jobs[d]->dc, [&, d] { return collect_job(*jobs[d], parts[d].data()); }));
+    int status = collect_job(*jobs[0], parts[0].data());
+    for (auto& f : fut) {
+        const int s2 = f.get();
+        if (status == ZK_OK) status = s2;
+    }
+    ZK_TRY(status);
+    memcpy(out, parts[0].data(), pbytes);
+    for (size_t d = 1; d < jobs.size(); d++) ZK_TRY(point_add_host(c, out, parts[d].data(), out));
+    hipSetDevice(g.devs[0]->device);
+    return ZK_OK;
 }
 
 API int zk_msm_device(zk_curve_t c, uint64_t handle, const void* d_scalars, uint64_t n, int mont, const zk_msm_opts* opts,
@@ -714,14 +855,10 @@ API int zk_msm(zk_curve_t c, uint64_t handle, const void* scalars_host, uint64_t
     return collect_job(*job, out);
 }
 
-API int zk_msm_batch_device(zk_curve_t c, uint64_t handle, const void* d_scalars, uint64_t n, uint32_t count, uint64_t stride_elems,
-                            int mont, const zk_msm_opts* opts, void* out, void* stream) {
-    if (count == 0) return ZK_OK;
-    if (!out || stride_elems < n || (n && (!d_scalars || !aligned16(d_scalars)))) return ZK_ERR_INVALID_ARG;
-    const BasesEntry* be = nullptr;
-    ZK_TRY(find_bases(handle, c, n, &be, opts));
-    const MsmTuning tu = tuning_from(opts);
-    DeviceCtx& dc = device_of(d_scalars);
+// `count` MSMs over one bases entry on ONE device (the scalars are in that device's memory): jobs of up to four vectors,
+// alternating over the device's two library streams, forked from and joined back into `stream`
+static int batch_on_device(DeviceCtx& dc, zk_curve_t c, const BasesEntry* be, const void* d_scalars, uint64_t n, uint32_t count, uint64_t stride_elems,
+                           int mont, const MsmTuning& tu, void* out, void* stream) {
     ZK_TRY(bind_device(dc));
     size_t pbytes = 0;
     CURVE_SWITCH(c, pbytes = (size_t)3 * 4 * coord_words<C>());
@@ -790,6 +927,74 @@ API int zk_msm_batch_device(zk_curve_t c, uint64_t handle, const void* d_scalars
             HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, dc.join_ev[s], 0));
         }
     }
+    return status;
+}
+
+API int zk_msm_batch_device(zk_curve_t c, uint64_t handle, const void* d_scalars, uint64_t n, uint32_t count, uint64_t stride_elems,
+                            int mont, const zk_msm_opts* opts, void* out, void* stream) {
+    if (count == 0) return ZK_OK;
+    if (!out || stride_elems < n || (n && (!d_scalars || !aligned16(d_scalars)))) return ZK_ERR_INVALID_ARG;
+    const BasesEntry* be = nullptr;
+    ZK_TRY(find_bases(handle, c, n, &be, opts));
+    const MsmTuning tu = tuning_from(opts);
+    DeviceCtx& owner = device_of(d_scalars);
+    const int G = (int)g.devs.size();
+    if (G == 1 || !whole_msm(tu) || n == 0) return batch_on_device(owner, c, be, d_scalars, n, count, stride_elems, mont, tu, out, stream);
+    const size_t pbytes = jac_bytes(c);
+    if (count < (uint32_t)G) {
+        // fewer vectors than devices (the L / R pair of an IPA round): every vector window-sharded over ALL devices, one after another
+        for (uint32_t v = 0; v < count; v++)
+            ZK_TRY(msm_fanout(c, *be, (const unsigned char*)d_scalars + (size_t)v * stride_elems * 32, &owner, (hipStream_t)stream, n, mont ? 1 : 0, tu,
+                              (unsigned char*)out + (size_t)v * pbytes));
+        return ZK_OK;
+    }
+    // at least one vector per device (halo2's column commitments): device d takes the WHOLE MSMs of vectors [count d / G, count (d + 1) / G)
+    // -- whole MSMs keep their fixed costs once per vector instead of once per vector and device -- and only those vectors
+    // travel (over xGMI, into the device's staging buffer, behind an event on the caller's stream)
+    hipEvent_t ready = nullptr;
+    {
+        ZK_TRY(bind_device(owner));
+        std::lock_guard<std::mutex> lk(owner.mu);
+        ZK_TRY(ensure_lib_streams(owner));
+        ready = owner.fork_ev;
+        HIP_TRY(hipEventRecord(ready, (hipStream_t)stream));
+    }
+    auto work = [&](int d) -> int {
+        DeviceCtx& dc = *g.devs[d];
+        const uint32_t first = (uint32_t)((uint64_t)count * d / G), last = (uint32_t)((uint64_t)count * (d + 1) / G);
+        if (last == first) return ZK_OK;
+        unsigned char* dst_out = (unsigned char*)out + (size_t)first * pbytes;
+        if (&dc == &owner)
+            return batch_on_device(dc, c, be, (const unsigned char*)d_scalars + (size_t)first * stride_elems * 32, n, last - first, stride_elems, mont, tu,
+                                   dst_out, stream);
+        ZK_TRY(bind_device(dc));
+        std::lock_guard<std::mutex> stage_lk(dc.batch_mu);      // the staging buffer serves one fanned-out batch at a time
+        {
+            std::lock_guard<std::mutex> lk(dc.mu);
+            ZK_TRY(ensure_lib_streams(dc));
+            ZK_TRY(ws_get(dc.batch_in, (size_t)(last - first) * n * 32));
+            HIP_TRY(hipStreamWaitEvent(dc.own, ready, 0));
+            for (uint32_t v = first; v < last; v++) {
+                const void* srcp = (const unsigned char*)d_scalars + (size_t)v * stride_elems * 32;
+                void* dstp = (unsigned char*)dc.batch_in.p + (size_t)(v - first) * n * 32;
+#if defined(ZK_EMU)
+                HIP_TRY(hipMemcpyAsync(dstp, srcp, n * 32, hipMemcpyDeviceToDevice, dc.own));
+#else
+                HIP_TRY(hipMemcpyPeerAsync(dstp, dc.device, srcp, owner.device, n * 32, dc.own));
+#endif
+            }
+        }
+        return batch_on_device(dc, c, be, dc.batch_in.p, n, last - first, n, mont, tu, dst_out, dc.own);
+    };
+    std::vector<std::future<int>> fut;
+    for (int d = 0; d < G; d++)
+        if (g.devs[d].get() != &owner) fut.push_back(run_on_device(*g.devs[d], [&, d] { return work(d); }));
+    int status = work(owner.index);
+    for (auto& f : fut) {
+        const int s2 = f.get();
+        if (status == ZK_OK) status = s2;
+    }
+    hipSetDevice(g.devs[0]->device);
     return status;
 }
 

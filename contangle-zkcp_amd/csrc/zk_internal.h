@@ -10,9 +10,14 @@
 #include <string.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "zk_rt.h"
@@ -76,6 +81,7 @@ struct MsmTuning {
     uint32_t big_thresh = 0;
     int limb_bits = 0;        // 32 forces the saturated path
     int waves = 0;
+    int window_group = 0;     // windows per group of a large single MSM (0 = automatic)
     bool no_hot_help = false;
     bool slice_reduce = false;   // the round-1 bucket reduction (slices + multiplier) instead of row / column sums
     bool device_partials = false;   // ZK_MSM_FLAG_DEVICE_PARTIALS: partial sums converted on the device, checked against the host's conversion
@@ -99,6 +105,8 @@ struct MsmJob {
     size_t host_cap = 0;
     hipEvent_t ev[8];                 // [0] begin .. [5] reduced, [6] partials on the host, [7] accumulate kernel done
     bool have_events = false;
+    std::vector<hipEvent_t> acc_ev;   // begin / end of the accumulate kernel, one pair per window group
+    int groups = 1;
     // what collect needs
     int (*finish)(MsmJob&, void* out_jac) = nullptr;
     int curve = 0, c = 0, w0 = 0, nw = 0;
@@ -125,6 +133,17 @@ struct StreamScratch {
     uint32_t ip_blocks = 0;            // partial sums per inner product waiting in `pinned` (zk_ipa_round_device)
 };
 
+// One persistent host thread per device of a multi-device process (zk_init_devices with n > 1): bound to its device once,
+// it runs that device's share of every fanned-out call -- enqueue, wait, the Horner tail of its MSM jobs -- so that the
+// shares proceed in parallel without a thread being created per call.
+struct DeviceWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::packaged_task<int()>> q;
+    bool stop = false;
+};
+
 constexpr int ZK_MAX_JOBS = 4;
 constexpr int ZK_MAX_STREAM_SCRATCH = 6;
 
@@ -141,7 +160,12 @@ struct DeviceCtx {
     uint64_t scratch_stamp = 0;
     MsmJob jobs[ZK_MAX_JOBS];
     hipStream_t side[2] = {nullptr, nullptr};   // library-owned streams: batched MSMs alternate between them
+    hipStream_t submit_streams[ZK_MAX_JOBS] = {nullptr, nullptr, nullptr, nullptr};   // ZK_MSM_FLAG_OWN_STREAM: one per MSM in flight
+    unsigned submit_rr = 0;
     hipStream_t own = nullptr;                  // library-owned stream of a device that is not the caller's (multi-device fan-out)
+    std::unique_ptr<DeviceWorker> worker;       // multi-device processes only
+    DevBuf batch_in;                            // scalar vectors of a fanned-out batch that live on a peer
+    std::mutex batch_mu;                        // ... one fanned-out batch at a time per device
     hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
     // NTT pass timing (zk_ntt_profile_enable): event pairs of the launches since the last read
     std::vector<hipEvent_t> ntt_ev_pool;
@@ -159,7 +183,7 @@ struct Ctx {
     std::map<uint64_t, BasesEntry> bases;
     uint64_t next_handle = 1;
     uint64_t next_ticket = 1;
-    std::map<uint64_t, MsmJob*> tickets;
+    std::map<uint64_t, std::vector<MsmJob*>> tickets;   // one job, or one per device of a fanned-out submission
     zk_msm_profile prof;      // of the last collected job
     zk_ntt_opts ntt_opts;     // process-wide NTT plan knobs (zk_ntt_configure)
     zk_msm_totals totals;     // sums over the collected jobs (zk_msm_profile_totals)

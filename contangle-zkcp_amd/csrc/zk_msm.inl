@@ -122,11 +122,16 @@ int msm_finish_impl(MsmJob& job, void* out_jac) {
         hipEventElapsedTime(&job.prof.hist_ms, job.ev[1], job.ev[2]);
         hipEventElapsedTime(&job.prof.scatter_ms, job.ev[2], job.ev[3]);
         hipEventElapsedTime(&job.prof.accumulate_ms, job.ev[3], job.ev[4]);
-        hipEventElapsedTime(&job.prof.accumulate_kernel_ms, job.ev[3], job.ev[7]);
+        job.prof.accumulate_kernel_ms = 0;          // the accumulate kernel of every window group
+        for (int gi = 0; gi < job.groups; gi++) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, job.acc_ev[2 * gi], job.acc_ev[2 * gi + 1]);
+            job.prof.accumulate_kernel_ms += ms;
+        }
         hipEventElapsedTime(&job.prof.reduce_ms, job.ev[4], job.ev[5]);
         hipEventElapsedTime(&job.prof.total_ms, job.ev[0], job.ev[5]);
         job.prof.total_ms += job.prof.host_tail_ms;
-        job.prof.groups = 1;
+        job.prof.groups = job.groups;
     }
     return ZK_OK;
 }
@@ -134,30 +139,13 @@ int msm_finish_impl(MsmJob& job, void* out_jac) {
 // C: the curve of the ABI call.  CK: the view the kernels compute in.  bases: device array of StoredAffine<CK>.
 // Enqueues every kernel of the MSM and the copy of the per-window partial sums on job.stream and returns; no host
 // synchronisation (workspace growth aside).
+// One window group [w0, w1) of the job: group `gi` of `ng` whose windows start `woff` windows into the job's range -- the whole
+// pipeline (sort, accumulate, reduction, copy of the partial sums) on job.stream, over workspaces sized for this group.
 template <class C, class CK>
-int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
+int msm_enqueue_group(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu,
+                      int c, int nwin, int w0, int w1, int gi, int ng, int woff, int nw_job) {
     hipStream_t st = job.stream;
-    memset(&job.prof, 0, sizeof job.prof);
-    job.dev_std = false;
-    job.finish = &msm_finish_impl<C, CK>;
-    job.empty = true;
-    const int c = msm_pick_c(n, tu.window_bits);
-    const int nwin = msm_windows<C>(c);
-    int w0 = 0, w1 = nwin;
-    if (!(tu.w0 == 0 && tu.w1 == 0)) {
-        w0 = tu.w0;
-        w1 = tu.w1;
-        if (w0 < 0 || w1 > nwin || w0 > w1) return ZK_ERR_INVALID_ARG;
-    }
-    job.c = c;
-    job.w0 = w0;
-    job.nw = w1 - w0;
-    job.batch = tu.batch ? tu.batch : 1;
-    job.prof.window_bits = c;
-    job.prof.windows_total = nwin;
-    job.prof.windows_done = w1 - w0;
-    job.prof.limb_bits = CK::EXT >= 29 ? 29 : 32;
-    if (n > 0 && w1 > w0) {
+    {
         if (n >= (1ull << 31)) return ZK_ERR_UNSUPPORTED;
         const int num_cus = job.dc->num_cus > 0 ? job.dc->num_cus : 256;
         MsmShape sh;
@@ -196,6 +184,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         {   // oversize threshold: 2x the mean bucket length + 64 (uniform 2^20 / c=16: mean 32, max ~70 -> none)
             const uint64_t mean = n / sh.nbk;
             sh.big_thresh = tu.big_thresh ? tu.big_thresh : (uint32_t)(2 * mean + 64);
+            sh.seg = msm_seg_len(n);
         }
         const int nw_all = sh.nw;
         // Bucket splitting: with fewer than ~4 work items per resident lane the accumulate kernel ends in a long drain (every
@@ -255,8 +244,8 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
             ZK_TRY(ws_get(job.subacc, ((size_t)nbuckets << sh.split_log) * sizeof(XYZZ<CK>)));
             acc_out = (XYZZ<CK>*)job.subacc.p;
         }
-        // oversized-bucket lists: a bucket above big_thresh yields ceil(cnt / MSM_SEG) segments
-        const size_t max_seg = ((size_t)n / MSM_SEG + (size_t)n / sh.big_thresh + 2) * nw_all;
+        // oversized-bucket lists: a bucket above big_thresh yields ceil(cnt / sh.seg) segments
+        const size_t max_seg = ((size_t)n / sh.seg + (size_t)n / sh.big_thresh + 2) * nw_all;
         ZK_TRY(ws_get(job.queue, sizeof(MsmQueue) + max_seg * (sizeof(MsmSeg) + 8) + 64));
         ZK_TRY(ws_get(job.seg_out, max_seg * sizeof(XYZZ<CK>)));
         MsmQueue* q = (MsmQueue*)job.queue.p;
@@ -272,7 +261,12 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         unsigned waves_per_simd = (unsigned)msm_acc_waves<CK>();
         if (tu.waves >= 1 && tu.waves <= 8) waves_per_simd = (unsigned)tu.waves;
         hipEvent_t* ev = job.ev;   // [0] begin, [1] counted, [2] staged, [3] sorted, [4] accumulated, [5] reduced, [6] partials on the host
-        HIP_TRY(hipEventRecord(ev[0], st));
+        if (gi == 0) HIP_TRY(hipEventRecord(ev[0], st));
+        while (job.acc_ev.size() < 2 * (size_t)ng) {      // one bracket of the accumulate kernel per window group
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            job.acc_ev.push_back(e);
+        }
         // ---- sort: partition the digits by (window, bucket range), then counting-sort every region in LDS
         const unsigned dblk = sh.sblk >= 4096 ? 1024u : 256u;   // small problems: fewer lanes, cheaper barriers
         if (pre)
@@ -326,7 +320,8 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
                       (const uint16_t*)stage_low, sh, (const uint32_t*)region_base, (const uint32_t*)wg_total, (const uint32_t*)hot_list, counts,
                       gcur, sorted, 1, hot_slices);
         HIP_TRY(hipMemsetAsync(q, 0, sizeof(MsmQueue), st));
-        HIP_TRY(hipEventRecord(ev[3], st));   // [3] -> [7] brackets the accumulate kernel alone
+        HIP_TRY(hipEventRecord(ev[3], st));   // [3] -> [7] brackets the accumulate kernel alone (per group: acc_ev)
+        HIP_TRY(hipEventRecord(job.acc_ev[2 * gi], st));
         // ---- persistent accumulate: lanes stream buckets, largest first; oversized buckets go to the cooperative segment
         // kernels (fixed grids over device-side lists, no host round trip)
         const uint32_t ntasks = (((nreg * ((sh.rb + MSM_RANKW - 1) / MSM_RANKW) * MSM_RANKW) << sh.split_log) + MSM_BATCH - 1) / MSM_BATCH;  // batches in the queue
@@ -335,13 +330,16 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         ZK_LAUNCH((msm_accumulate_kernel<CK>), acc_grid, 64, 0, st, bases, (const uint32_t*)sorted, (const uint32_t*)offs,
                   (const uint32_t*)counts, (const uint32_t*)order, acc_out, sh, q, seg_list, big_list);
         HIP_TRY(hipEventRecord(ev[7], st));
+        HIP_TRY(hipEventRecord(job.acc_ev[2 * gi + 1], st));
         if (sh.split_log > 0)
             ZK_LAUNCH((msm_combine_sub_kernel<CK>), (nbuckets + 63) / 64, 64, 0, st, (const XYZZ<CK>*)acc_out, buckets, nbuckets, sh.split_log);
         const unsigned big_grid = max_seg < 4096 ? (unsigned)max_seg : 4096u;
         ZK_LAUNCH((msm_accumulate_big_kernel<CK>), big_grid, 64, 0, st, bases, (const uint32_t*)sorted, (const MsmQueue*)q,
                   (const MsmSeg*)seg_list, seg_out);
-        ZK_LAUNCH((msm_combine_big_kernel<CK>), big_grid < 64 ? big_grid : 64u, tree_lanes<CK>(), 0, st, (const MsmQueue*)q,
-                  (const uint32_t*)big_list, (const uint32_t*)counts, (const XYZZ<CK>*)seg_out, buckets);
+        // (an oversized bucket holds more than big_thresh entries: at most n nw / big_thresh of them exist)
+        const size_t max_big = (size_t)n * nw_all / sh.big_thresh + 1;
+        ZK_LAUNCH((msm_combine_big_kernel<CK>), (unsigned)(max_big < 2048 ? max_big : 2048), tree_lanes<CK>(), 0, st, (const MsmQueue*)q,
+                  (const uint32_t*)big_list, (const uint32_t*)counts, (const XYZZ<CK>*)seg_out, buckets, sh.seg);
         HIP_TRY(hipEventRecord(ev[4], st));
         uint32_t per = 0;
         job.axes = !tu.slice_reduce;
@@ -427,23 +425,78 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
         }
         HIP_TRY(hipEventRecord(ev[5], st));
         HIP_TRY(hipGetLastError());
-        const size_t hbytes = (size_t)nw_all * per * (sizeof(XYZZ<CK>) + (job.dev_std ? sizeof(XYZZ<C>) + 4 * (size_t)partial_dbg_words<CK>() : 0));
-        if (job.host_cap < hbytes) {
+        const size_t pbytes1 = sizeof(XYZZ<CK>) + (job.dev_std ? sizeof(XYZZ<C>) + 4 * (size_t)partial_dbg_words<CK>() : 0);
+        const size_t hbytes = (size_t)nw_all * per * pbytes1;
+        const size_t hbytes_job = (ng > 1 ? (size_t)nw_job : (size_t)nw_all) * per * pbytes1;     // (groups: batch == 1, no diagnostic form)
+        if (gi == 0 && job.host_cap < hbytes_job) {
             if (job.host_partials) hipHostFree(job.host_partials);
             job.host_partials = nullptr;
             job.host_cap = 0;
-            HIP_TRY(hipHostMalloc(&job.host_partials, hbytes + 4096, 0));
-            job.host_cap = hbytes + 4096;
+            HIP_TRY(hipHostMalloc(&job.host_partials, hbytes_job + 4096, 0));
+            job.host_cap = hbytes_job + 4096;
         }
-        HIP_TRY(hipMemcpyAsync(job.host_partials, cur, hbytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync((unsigned char*)job.host_partials + (size_t)woff * per * pbytes1, cur, hbytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(ev[6], st));
         job.per = per;
         job.empty = false;
-        job.alg_bytes = (double)job.batch * (double)n_real * (sizeof(Fe<typename C::Fr>) + sizeof(Affine<C>)) * (double)(w1 - w0) / (double)nwin;
+        job.alg_bytes += (double)job.batch * (double)n_real * (sizeof(Fe<typename C::Fr>) + sizeof(Affine<C>)) * (double)(w1 - w0) / (double)nwin;
     }
     return ZK_OK;
 }
 
+
+// C: the curve of the ABI call.  CK: the view the kernels compute in.  bases: device array of StoredAffine<CK>.
+// Enqueues every kernel of the MSM and the copy of the per-window partial sums on job.stream and returns; no host
+// synchronisation (workspace growth aside).
+// Window groups: the windows of a large single MSM are processed a few at a time.  All windows at once keep n x windows sorted
+// entries (4 B each) plus the bases live while the accumulate kernel gathers -- 268 MB + 256 MB for 2^22 points x 16 windows,
+// past the 256 MiB Infinity Cache -- and the gathers then come from HBM; 4 windows at a time (64 MB of entries) were measured at
+// 1.82 ms against 8.68 / 4 = 2.17 ms (round 2, tools/shard_model.py BN254 2^22).  The groups are just window ranges of the
+// same job: each runs the whole pipeline over workspaces sized for a group, and the partial sums of all windows land in one
+// host buffer for the usual Horner.  Auto: groups of 2^24 / n windows from 2^21 points up; zk_msm_opts.window_group overrides.
+template <class C, class CK>
+int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
+    memset(&job.prof, 0, sizeof job.prof);
+    job.dev_std = false;
+    job.finish = &msm_finish_impl<C, CK>;
+    job.empty = true;
+    job.alg_bytes = 0;
+    const int c = msm_pick_c(n, tu.window_bits);
+    const int nwin = msm_windows<C>(c);
+    int w0 = 0, w1 = nwin;
+    if (!(tu.w0 == 0 && tu.w1 == 0)) {
+        w0 = tu.w0;
+        w1 = tu.w1;
+        if (w0 < 0 || w1 > nwin || w0 > w1) return ZK_ERR_INVALID_ARG;
+    }
+    job.c = c;
+    job.w0 = w0;
+    job.nw = w1 - w0;
+    job.batch = tu.batch ? tu.batch : 1;
+    job.prof.window_bits = c;
+    job.prof.windows_total = nwin;
+    job.prof.windows_done = w1 - w0;
+    job.prof.limb_bits = CK::EXT >= 29 ? 29 : 32;
+    job.groups = 1;
+    if (n == 0 || w1 <= w0) return ZK_OK;
+    int gw = w1 - w0;                                  // windows per group
+    if (job.batch == 1 && !tu.precomputed && !tu.device_partials) {
+        if (tu.window_group > 0)
+            gw = tu.window_group;
+        else if (n >= (1ull << 21))
+            gw = (int)((1ull << 24) / n);
+        if (gw < 1) gw = 1;
+        if (gw > w1 - w0) gw = w1 - w0;
+    }
+    const int ng = (w1 - w0 + gw - 1) / gw;
+    gw = (w1 - w0 + ng - 1) / ng;                      // even groups
+    job.groups = ng;
+    for (int gi = 0; gi < ng; gi++) {
+        const int a = w0 + gi * gw, b = a + gw < w1 ? a + gw : w1;
+        ZK_TRY((msm_enqueue_group<C, CK>(job, bases, d_scalars, n, mont, tu, c, nwin, a, b, gi, ng, a - w0, w1 - w0)));
+    }
+    return ZK_OK;
+}
 
 // every curve runs its bucket arithmetic in the lazy-limb view (Pallas, Vesta, BN254: 9 x 29-bit limbs; BLS12-381: 14 x 28;
 // G2 as pairs of those); zk_msm_opts.limb_bits = 32 forces the saturated 32-bit path

@@ -50,6 +50,7 @@ struct MsmShape {
     uint32_t batch;       // scalar vectors summed over the same bases by this job; nw = batch * nwb windows in all, window-major per vector
     int nwb;              // windows per scalar vector
     uint64_t batch_stride;   // elements between the scalar vectors
+    uint32_t seg;         // entries per cooperative segment of an oversized bucket (power of two in [128, MSM_SEG_MAX], from n: msm_seg_len)
     uint32_t pre_n;       // precomputed-table form (ZK_MSM_FLAG_PRECOMPUTED): the real point count; n = pre_w * pre_n table entries,
     uint32_t pre_w;       // ONE bucket set (nwb = 1): entry w * pre_n + i = the digit of scalar i in window w, point [2^(c w)] P_i
 };
@@ -580,8 +581,17 @@ __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t* __restri
 // (longest-processing-time order, so the SIMDs finish together).  Task t = (rank r, range g): lane l sums
 // bucket order[g*rb + 64 r + l].  Buckets longer than sh.big_thresh (a few times the mean length: skewed
 // witnesses, e.g. the 25% of unit scalars of a Groth16 assignment) are not summed by one lane: they are cut
-// into segments of MSM_SEG entries appended to `seg_list` for msm_accumulate_big_kernel.
-constexpr uint32_t MSM_SEG = 2048;   // entries per cooperative segment (one wave: <= 32 adds per lane + a 6-level tree)
+// into segments of sh.seg entries appended to `seg_list` for msm_accumulate_big_kernel.
+// Entries per cooperative segment (one wave: len / 64 additions per lane + a 6-level tree).  The worst oversized bucket of a
+// Groth16 assignment holds the unit scalars, a quarter of all entries: with 2048-entry segments a 2^20-point MSM cuts it into
+// 128 segments -- 128 waves on 1024 SIMDs, each doing 38 dependent additions (1.35 ms per G2 launch in round 2).  The length
+// now follows n so that such a bucket yields ~1024 segments: n / 4096, at least 128 (below that the tree dominates).
+constexpr uint32_t MSM_SEG_MAX = 2048;
+inline uint32_t msm_seg_len(uint64_t n) {
+    uint32_t s = 128;
+    while (s < MSM_SEG_MAX && (uint64_t)s * 4096 < n) s <<= 1;
+    return s;
+}
 
 // lanes per workgroup of the LDS tree kernels: 256 XYZZ points must fit the 64 KiB static LDS limit (G2: 384 B each)
 template <class C>
@@ -714,7 +724,7 @@ __global__ void __launch_bounds__(64, msm_acc_waves<C>()) msm_accumulate_kernel(
                         xyzz_set_inf(acc);
                         buckets[out_slot] = acc;   // the cooperative path below owns this bucket
                         if (piece == 0) {   // (no `continue` here: every lane must reach the wave votes below)
-                            const uint32_t ns = (cnt + MSM_SEG - 1) / MSM_SEG;
+                            const uint32_t ns = (cnt + sh.seg - 1) / sh.seg;
                             const uint32_t bi = atomicAdd(&q->nbig, 1u);
                             const uint32_t s0 = atomicAdd(&q->nseg, ns);
                             big_list[2 * bi] = gb;
@@ -722,8 +732,8 @@ __global__ void __launch_bounds__(64, msm_acc_waves<C>()) msm_accumulate_kernel(
                             for (uint32_t k = 0; k < ns; k++) {
                                 MsmSeg sg;
                                 sg.bucket = gb;
-                                sg.start = start + k * MSM_SEG;
-                                sg.len = (k + 1 == ns) ? cnt - k * MSM_SEG : MSM_SEG;
+                                sg.start = start + k * sh.seg;
+                                sg.len = (k + 1 == ns) ? cnt - k * sh.seg : sh.seg;
                                 sg.big_index = bi;
                                 seg_list[s0 + k] = sg;
                             }
@@ -810,18 +820,23 @@ __global__ void __launch_bounds__(64) msm_accumulate_big_kernel(const StoredAffi
     }
 }
 
-// bucket = sum of its segments (one workgroup per oversized bucket; segment counts are small: cnt / MSM_SEG)
+// bucket = sum of its segments: one workgroup per oversized bucket (the grid covers every bucket that can be oversized, the
+// others leave at once).  Every addition in here is a DEPENDENT one (~36 us each on the BLS12-381 G2 point type at one wave per
+// SIMD), so the shape matters more than the count: a lane adds ceil(ns / TL) segments, then the tree runs over the lanes that
+// hold something only -- two segments cost one addition, not a 7-level tree -- and a workgroup never takes a second bucket
+// while others idle (round 2: 64 workgroups x ~4 buckets x 8 levels = 0.83 ms per G2 launch of a Groth16 witness).
 template <class C>
 __global__ void __launch_bounds__(256) msm_combine_big_kernel(const MsmQueue* __restrict__ q, const uint32_t* __restrict__ big_list,
                                                               const uint32_t* __restrict__ counts, const XYZZ<C>* __restrict__ seg_out,
-                                                              XYZZ<C>* __restrict__ buckets) {
+                                                              XYZZ<C>* __restrict__ buckets, uint32_t seg) {
     constexpr uint32_t TL = tree_lanes<C>();
     __shared__ XYZZ<C> sh[TL];
     const uint32_t tid = threadIdx.x;
     const uint32_t nbig = q->nbig;
     for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
         const uint32_t gb = big_list[2 * b], s0 = big_list[2 * b + 1];
-        const uint32_t ns = (counts[gb] + MSM_SEG - 1) / MSM_SEG;
+        const uint32_t ns = (counts[gb] + seg - 1) / seg;
+        const uint32_t live = ns < TL ? ns : TL;              // lanes that hold a partial sum
         XYZZ<C> acc;
         xyzz_set_inf(acc);
         for (uint32_t k = tid; k < ns; k += TL) {
@@ -830,8 +845,10 @@ __global__ void __launch_bounds__(256) msm_combine_big_kernel(const MsmQueue* __
         }
         sh[tid] = acc;
         __syncthreads();
-        for (uint32_t d = TL / 2; d > 0; d >>= 1) {
-            if (tid < d) {
+        uint32_t top = 1;
+        while (top < live) top <<= 1;
+        for (uint32_t d = top >> 1; d > 0; d >>= 1) {
+            if (tid < d && tid + d < live) {
                 XYZZ<C> v = sh[tid + d];
                 xyzz_add(acc, v);
                 sh[tid] = acc;

@@ -1,6 +1,8 @@
 // Launch sequences of the halo2 prover steps beyond commit / FFT (zk_poly_kernels.h).  Included by zk_ntt.inl, once per
 // scalar field.  Scratch (numerators / denominators, block totals, partial sums) belongs to the caller's stream.
 #pragma once
+#include <map>
+#include <utility>
 #include "zk_poly_kernels.h"
 namespace zk {
 
@@ -397,6 +399,28 @@ int expr_compile29(const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, cons
     std::vector<B> st;
     words.clear();
     auto emit = [&](uint32_t op, int rot, uint32_t arg) { words.push_back((uint64_t)op | ((uint64_t)(uint16_t)rot << 16) | ((uint64_t)arg << 32)); };
+    // column-value slots: next_use[k] = the next COL op reading the same (column, rotation), the eviction key (farthest first)
+    const uint32_t NEVER = 0xffffffffu;
+    std::vector<uint32_t> next_use(n_ops, NEVER);
+    {
+        std::map<std::pair<uint32_t, int>, uint32_t> last;
+        for (uint32_t k = n_ops; k-- > 0;)
+            if (prog[k].op == 0) {
+                const auto key = std::make_pair(prog[k].arg, (int)prog[k].rot);
+                auto it = last.find(key);
+                if (it != last.end()) next_use[k] = it->second;
+                last[key] = k;
+            }
+    }
+    struct Slot {
+        bool used = false;
+        uint32_t col = 0;
+        int rot = 0;
+        uint32_t next = 0;
+    } slots[EXPR29_SLOTS];
+    uint32_t nslots = EXPR29_SLOTS, hoist = 12;
+    if (const char* e = getenv("ZK_EXPR29_SLOTS")) nslots = (uint32_t)atoi(e) >= 1 && (uint32_t)atoi(e) <= EXPR29_SLOTS ? (uint32_t)atoi(e) : nslots;   // DIAGNOSTIC (temporary)
+    if (const char* e = getenv("ZK_EXPR29_HOIST")) hoist = (uint32_t)atoi(e);
     auto norm_top = [&]() {
         emit(EXPR29_NORM, 0, 0);
         st.back().lb = NP;
@@ -443,7 +467,28 @@ int expr_compile29(const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, cons
                 if (st.back().vb > 32) refresh_top();
                 if (st.back().lb > NP) norm_top();
             }
-            emit(o.op, o.op == 0 ? o.rot : 0, o.arg);
+            if (o.op == 0) {                   // the cell from its slot; a miss loads it first (hoisted below)
+                int sl = -1;
+                for (uint32_t q = 0; q < nslots; q++)
+                    if (slots[q].used && slots[q].col == o.arg && slots[q].rot == (int)o.rot) sl = (int)q;
+                if (sl < 0) {
+                    for (uint32_t q = 0; q < nslots && sl < 0; q++)
+                        if (!slots[q].used) sl = (int)q;
+                    if (sl < 0) {
+                        sl = 0;
+                        for (uint32_t q = 1; q < nslots; q++)
+                            if (slots[q].next > slots[sl].next) sl = (int)q;
+                    }
+                    emit(EXPR29_LOAD, o.rot, o.arg | ((uint32_t)sl << 16));
+                    slots[sl].used = true;
+                    slots[sl].col = o.arg;
+                    slots[sl].rot = o.rot;
+                }
+                slots[sl].next = next_use[k];
+                emit(0, 0, (uint32_t)sl);
+            } else {
+                emit(1, 0, o.arg);
+            }
             st.push_back(LOAD_B);
             if (st.size() > EXPR_STACK) return ZK_ERR_UNSUPPORTED;
             if (st.size() - 1 > depth) depth = (uint32_t)st.size() - 1;
@@ -488,6 +533,22 @@ int expr_compile29(const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, cons
     if (st.size() != 1) return ZK_ERR_INVALID_ARG;
     if (st.back().vb > 64) refresh_top();      // fe29_to_std: norm, product by R mod p, canonical (value < 20 p after the product)
     if (words.size() > 2 * EXPR_MAX_OPS) return ZK_ERR_UNSUPPORTED;
+    // hoist every load up to 12 operations ahead of its first use (never across another operation on the same slot): a load has
+    // no effect on the stack, and issued early its latency is spent under the products in between
+    for (size_t q = 0; q < words.size(); q++) {
+        const uint64_t ld = words[q];
+        if ((ld & 0xff) != EXPR29_LOAD) continue;
+        const uint32_t slot = (uint32_t)(ld >> 48);
+        size_t at = q;
+        while (at > 0 && q - at < hoist) {
+            const uint64_t prev = words[at - 1];
+            const uint32_t pop = (uint32_t)(prev & 0xff);
+            if ((pop == EXPR29_LOAD && (uint32_t)(prev >> 48) == slot) || (pop == 0 && (uint32_t)(prev >> 32) == slot)) break;
+            words[at] = prev;
+            at--;
+        }
+        words[at] = ld;
+    }
     depth_out = depth;
     return ZK_OK;
 }

@@ -609,12 +609,17 @@ __global__ void __launch_bounds__(EXPR_WG) expr_eval_kernel(const uint64_t* __re
 // per stack slot, picks the bias table of every subtraction / negation, and inserts the carry steps (EXPR29_NORM) and value
 // contractions (EXPR29_REFRESH: a product by R' mod p) that keep every product's operands inside fe29_mul's precondition.
 // The kernel only executes: it never decides anything about bounds.
-//   ops: 0 col  1 const  2 add  3 sub(arg = bias id)  4 mul  5 neg(arg = bias id)  6 scale(arg = const)  7 norm  8 refresh
+//   ops: 0 push slot(arg = slot)  1 const  2 add  3 sub(arg = bias id)  4 mul  5 neg(arg = bias id)  6 scale(arg = const)  7 norm
+//        8 refresh  9 load(arg = column | slot << 16, rot): slot <- column[row + rot]
 //   bias ids: 0 BIAS4K1  1 BIAS4K2  2 BIAS8K2  3 BIAS8K3  4 BIAS16K2
+// Column values go through EXPR29_SLOTS register slots per lane: a gate expression reads the same (column, rotation) several
+// times (a^5 is five reads of a when the AST is walked as upstream does) and every read is 32 B per row from L2 / HBM -- the
+// bench's program has 99 reads of 37 distinct cells; two slots with farthest-next-use eviction (the host knows the whole
+// program) leave 69, four would leave 51.  The host also hoists every load a few operations ahead of its first use.
 // One wave per workgroup (the stacks are per lane: no barrier anywhere); the LDS stack is sized by the program's depth, so
 // shallow programs get more resident waves to hide the column loads behind.
-constexpr uint32_t EXPR29_WG = 64;
-enum : uint32_t { EXPR29_NORM = 7, EXPR29_REFRESH = 8 };
+constexpr uint32_t EXPR29_WG = 64, EXPR29_SLOTS = 2;   // (4 slots: see the note at the slot array below)
+enum : uint32_t { EXPR29_NORM = 7, EXPR29_REFRESH = 8, EXPR29_LOAD = 9 };
 
 template <class F>
 __device__ __forceinline__ void fe29_sub_by_id(Fe29<F>& r, const Fe29<F>& a, const Fe29<F>& b, uint32_t id) {
@@ -640,15 +645,31 @@ __global__ void __launch_bounds__(EXPR29_WG) expr_eval29_kernel(const uint64_t* 
     constexpr int L = K::L;
     const uint32_t lane = threadIdx.x;
     const uint64_t n = 1ull << log_n, mask = n - 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + lane; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    // a wave-uniform row loop (the whole wave takes rows base .. base + 63): the program words are then scalar loads and every
+    // branch on an opcode is a scalar branch; lanes past the end (only when n < 64) compute on wrapped rows and store nothing
+    for (uint64_t base = (uint64_t)blockIdx.x * EXPR29_WG; base < n; base += (uint64_t)gridDim.x * EXPR29_WG) {
+        const uint64_t i = base + lane;
         uint32_t sp = 0;
         Fe29<F> tos;
         fe29_zero(tos);
+        // the column-value slots.  TWO of them: with four (named registers c0 .. c3 selected by an if-chain on the wave-uniform slot
+        // number) the gfx950 build returned wrong rows as soon as slots 2 / 3 were in use -- in the ISA a load into slot 3 also
+        // overwrote slot 2 -- while one and two slots, and the CPU build of the same source with four, were right
+        // (profiles/r03_b_expr29_slots.txt: the matrix of slot counts x load hoisting on the GPU).
+        uint32_t cs[EXPR29_SLOTS * F::N];
+        ZK_UNROLL
+        for (uint32_t q = 0; q < EXPR29_SLOTS * F::N; q++) cs[q] = 0;
         for (uint32_t k = 0; k < n_ops; k++) {
-            const uint64_t w = prog[k];
+            const uint64_t w = prog[ZK_UNIFORM32(k)];          // (k is wave-uniform: a scalar load)
             const uint32_t op = (uint32_t)(w & 0xff), arg = (uint32_t)(w >> 32);
             const int32_t rot = (int32_t)(int16_t)(uint16_t)(w >> 16);
-            if (op <= 1) {
+            if (op == EXPR29_LOAD) {
+                const uint32_t col = arg & 0xffffu, slot = (arg >> 16) & (EXPR29_SLOTS - 1);
+                const uint64_t j = (i + (uint64_t)((int64_t)rot * (int64_t)rot_scale)) & mask;
+                const Fe<F> raw = cols[col < n_cols ? col : 0][j];
+                ZK_UNROLL
+                for (int l = 0; l < F::N; l++) cs[slot * F::N + l] = raw.v[l];
+            } else if (op <= 1) {
                 if (sp > depth) break;
                 if (sp >= 1) {
                     ZK_UNROLL
@@ -656,8 +677,9 @@ __global__ void __launch_bounds__(EXPR29_WG) expr_eval29_kernel(const uint64_t* 
                 }
                 Fe<F> raw;
                 if (op == 0) {
-                    const uint64_t j = (i + (uint64_t)((int64_t)rot * (int64_t)rot_scale)) & mask;
-                    raw = cols[arg < n_cols ? arg : 0][j];
+                    const uint32_t slot = arg & (EXPR29_SLOTS - 1);
+                    ZK_UNROLL
+                    for (int l = 0; l < F::N; l++) raw.v[l] = cs[slot * F::N + l];
                 } else {
                     raw = consts[arg < n_consts ? arg : 0];
                 }
@@ -693,7 +715,7 @@ __global__ void __launch_bounds__(EXPR29_WG) expr_eval29_kernel(const uint64_t* 
         }
         Fe<F> r;
         fe29_to_std(r, tos);      // x R' -> x R, canonical (the host left tos normalised enough for this product)
-        out[i] = r;
+        if (i < n) out[i] = r;
     }
 }
 

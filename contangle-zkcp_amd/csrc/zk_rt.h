@@ -14,4 +14,5 @@
 #define ZK_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 #define ZK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), (stream), __VA_ARGS__)
+#define ZK_UNIFORM32(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))   // a value the whole wave agrees on, as a scalar
 #endif

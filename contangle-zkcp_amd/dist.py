@@ -151,7 +151,7 @@ def msm_many_sharded(jobs, window_bits=0, group=None, stream=0):
                     tickets[i] = t.collect()
                     break
         tickets.append(msm_submit(bases, sc, montgomery=mont, window_bits=window_bits, windows=(lo, hi) if world > 1 else None,
-                                  stream=stream, base_offset=base_offset))
+                                  stream=stream, base_offset=base_offset, own_stream=True))     # (the scalars stay untouched until the collects below)
     parts = []
     for c, t in zip(curves, tickets):
         parts.append(_identity(c) if t is None else (t if isinstance(t, np.ndarray) else t.collect()))

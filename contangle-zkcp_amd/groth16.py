@@ -127,14 +127,15 @@ class Prover:
         d_h = witness_map(self.field, self.A, self.B, self.C, d_z, ni, d_abc[0], d_abc[1], d_abc[2], stream=stream)
         d_zc = self.to_device(z_mont)
         vec_op(self.field, "into_repr", d_zc, stream=stream)             # the MSMs over z take canonical BigInts, like upstream
-        # at most four MSMs in flight per device: submit four, collect one, submit the fifth
-        t_h = msm_submit(self.h_query, d_h[:m - 1], montgomery=True, stream=stream)
-        t_l = msm_submit(self.l_query, d_zc[ni:], stream=stream)
-        t_a = msm_submit(self.a_query, d_zc[1:], stream=stream)
-        t_b1 = msm_submit(self.b_g1_query, d_zc[1:], stream=stream)
-        accs = {"h_acc": t_h.collect()}
-        t_b2 = msm_submit(self.b_g2_query, d_zc[1:], stream=stream)
-        accs.update(l_acc=t_l.collect(), a_acc=t_a.collect(), b_g1_acc=t_b1.collect(), b_g2_acc=t_b2.collect())
+        # at most four MSMs in flight per device: submit four, collect one, submit the fifth.  The G2 MSM goes first: its host
+        # tail (the Horner over the windows on Fq2 host limbs) is the longest of the five and then runs beside the G1 MSMs' device work
+        t_b2 = msm_submit(self.b_g2_query, d_zc[1:], stream=stream, own_stream=True)
+        t_h = msm_submit(self.h_query, d_h[:m - 1], montgomery=True, stream=stream, own_stream=True)
+        t_l = msm_submit(self.l_query, d_zc[ni:], stream=stream, own_stream=True)
+        t_a = msm_submit(self.a_query, d_zc[1:], stream=stream, own_stream=True)
+        accs = {"b_g2_acc": t_b2.collect()}
+        t_b1 = msm_submit(self.b_g1_query, d_zc[1:], stream=stream, own_stream=True)
+        accs.update(h_acc=t_h.collect(), l_acc=t_l.collect(), a_acc=t_a.collect(), b_g1_acc=t_b1.collect())
         a, b, c = assemble_proof(self.pairing, self.points, accs, r_mont, s_mont)
         return (a, b, c), ark_serialize.proof_to_bytes(self.pairing, a, b, c)
 

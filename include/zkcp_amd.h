@@ -84,12 +84,18 @@ typedef struct {
     int waves_per_simd; /* accumulate-kernel waves launched per SIMD; 0 = what the kernel was compiled for */
     int flags;          /* ZK_MSM_FLAG_* */
     int base_offset;    /* use bases [base_offset, base_offset + n) of the handle (halo2's IPA works on halves of one generator vector) */
-    int reserved[2];
+    int window_group;   /* windows processed at a time by a large single MSM (sorted entries + bases should stay inside the 256 MiB Infinity
+                         * Cache); 0 = automatic: 2^24 / n windows from 2^21 points up, all at once below */
+    int reserved;
 } zk_msm_opts;
 #define ZK_MSM_FLAG_NO_HOT_HELP 1   /* skewed witnesses: leave hot regions to their own sort workgroup */
 #define ZK_MSM_FLAG_SLICE_REDUCE 2  /* bucket reduction by slices + multiplier (round 1) instead of row / column sums: A/B */
 #define ZK_MSM_FLAG_PRECOMPUTED 4   /* ONE bucket set over the handle's table of window multiples (zk_bases_precompute first): no per-window
                                      * reduction, no host Horner; whole MSMs over the whole handle only */
+#define ZK_MSM_FLAG_OWN_STREAM 16    /* zk_msm_submit only: run the job on a library stream forked behind the work `hip_stream` holds at the call (it sees
+                                     * the scalars that work produces), alternating between two streams, so that MSMs submitted back to back overlap --
+                                     * the G2 MSM of a Groth16 proof spends ~4 ms in dependent additions that leave the GPU idle.  Nothing enqueued on
+                                     * `hip_stream` afterwards waits for the job: the scalars must stay untouched until zk_msm_collect. */
 #define ZK_MSM_FLAG_DEVICE_PARTIALS 8 /* diagnostic: the lazy-limb partial sums are converted to the caller's limb form on the device, the result
                                        * is built from those, and every one is checked against the host's conversion: zk_msm_profile.reserved =
                                        * mismatches (low 24 bits) | first differing conversion stage << 24 | its component << 28 */
@@ -108,7 +114,7 @@ typedef struct {
 typedef struct {
     float digits_ms, hist_ms, scatter_ms, accumulate_ms, reduce_ms, host_tail_ms, total_ms;
     int window_bits, windows_total, windows_done;
-    int groups;      /* always 1 (a two-stream window-group pipeline was measured slower and removed) */
+    int groups;      /* window groups the job ran in (zk_msm_opts.window_group): with more than one, the per-phase times are those of the last group; total_ms and accumulate_kernel_ms cover all */
     int limb_bits;   /* bucket arithmetic of the call: 29 = lazy unsaturated limbs (9 x 29 bits; BLS12-381 14 x 28; pairs of those on G2), 32 = saturated words */
     float accumulate_kernel_ms;   /* msm_accumulate_kernel alone (accumulate_ms also covers the piece / segment combine kernels) */
     int reserved;    /* ZK_MSM_FLAG_DEVICE_PARTIALS: see there; 0 otherwise */

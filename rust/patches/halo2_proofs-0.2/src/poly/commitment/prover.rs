@@ -57,9 +57,8 @@ pub fn ipa_rounds_device<C: CurveAffine, E: EncodedChallenge<C>, R: RngCore, T: 
         let u_j_inv = u_j.invert().unwrap();
         // p'[i] += u_j^-1 p'[i + half] ; b[i] += u_j b[i + half] ; the generators' fold goes into the weights
         let (ui, uu) = (limbs_of(&u_j_inv), limbs_of(&u_j));
-        zk::check(unsafe { zk::zk_vec_fold_device(field, d_p.ptr(), half, ui.as_ptr() as _, stream) }, "zk_vec_fold_device").unwrap();
-        zk::check(unsafe { zk::zk_vec_fold_device(field, d_b.ptr(), half, uu.as_ptr() as _, stream) }, "zk_vec_fold_device").unwrap();
-        zk::check(unsafe { zk::zk_ipa_update_weights_device(field, d_w.ptr(), m0, half, uu.as_ptr() as _, stream) }, "zk_ipa_update_weights_device").unwrap();
+        let _ = ui; // (the library inverts u_j itself: the three folds are one launch)
+        zk::check(unsafe { zk::zk_ipa_fold_round_device(field, d_p.ptr(), d_b.ptr(), d_w.ptr(), half, m0, uu.as_ptr() as _, stream) }, "zk_ipa_fold_round_device").unwrap();
         cur = half;
         f += &(l_j_randomness * &u_j_inv);
         f += &(r_j_randomness * &u_j);

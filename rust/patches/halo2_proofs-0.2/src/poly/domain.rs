@@ -18,6 +18,22 @@ impl<G: Group> EvaluationDomain<G> {
                                                   core::ptr::null(), stream) };
         zk::check(st, "zk_ntt_extend_device").unwrap();
     }
+    /// Both forms of a column are kept (coefficients for the openings, the extended coset for the quotient): out of place, no copy.
+    /// `lazy_out`: the coset values leave in the radix the lazy-limb quotient evaluator reads (ZK_NTT_OUT_R29, one constant of the
+    /// last pass).  `part` of `parts`: only the sub-coset ZETA extended_omega^(i parts + part) (a sharded quotient, one part per GPU).
+    pub fn lagrange_to_coeff_to(&self, field: i32, lagrange: &zk::DeviceBuf, coeffs: &mut zk::DeviceBuf, stream: *mut core::ffi::c_void) {
+        let w = limbs_of(&self.omega_inv);
+        zk::check(unsafe { zk::zk_ntt_oop_device(field, lagrange.ptr() as _, coeffs.ptr(), self.k, self.k, w.as_ptr() as _, 1, core::ptr::null(),
+                                                 core::ptr::null(), stream) }, "zk_ntt_oop_device").unwrap();
+    }
+    pub fn coeff_to_extended_part_to(&self, field: i32, coeffs: &zk::DeviceBuf, out: &mut zk::DeviceBuf, part: u32, parts: u32, lazy_out: bool,
+                                     stream: *mut core::ffi::c_void) {
+        let g = limbs_of(&(self.g_coset * self.extended_omega.pow_vartime([part as u64])));
+        let w = limbs_of(&self.extended_omega.pow_vartime([parts as u64]));
+        let log_len = self.extended_k - parts.trailing_zeros();
+        zk::check(unsafe { zk::zk_ntt_oop_device(field, coeffs.ptr() as _, out.ptr(), log_len, self.k, w.as_ptr() as _, if lazy_out { 2 } else { 0 },
+                                                 g.as_ptr() as _, core::ptr::null(), stream) }, "zk_ntt_oop_device").unwrap();
+    }
     /// best_fft(a, extended_omega_inv) ; * extended_ifft_divisor ; distribute_powers_zeta(a, false) ; truncate to n * (j - 1)
     pub fn extended_to_coeff_device(&self, field: i32, a_ext: &mut zk::DeviceBuf, stream: *mut core::ffi::c_void) {
         let (w, zi) = (limbs_of(&self.extended_omega_inv), limbs_of(&self.g_coset_inv));

@@ -36,7 +36,8 @@ pub struct zk_msm_opts {
     pub waves_per_simd: c_int,
     pub flags: c_int,
     pub base_offset: c_int,
-    pub reserved: [c_int; 2],
+    pub window_group: c_int,
+    pub reserved: c_int,
 }
 #[repr(C)]
 #[derive(Default, Clone, Copy)]

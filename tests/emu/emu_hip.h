@@ -50,6 +50,7 @@ const uint32_t* wave_exchange(uint32_t v);
 
 #define ZK_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(emu::g_dyn_smem)
 #define ZK_EMU_STRIP_PARENS(...) __VA_ARGS__
+#define ZK_UNIFORM32(v) ((uint32_t)(v))
 #define ZK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     emu::launch((unsigned)(grid), (unsigned)(block), (size_t)(shmem), [&]() { (ZK_EMU_STRIP_PARENS kernel)(__VA_ARGS__); })
 

@@ -283,6 +283,26 @@ def check_msm_sort_shapes(zk, cname, n, window_bits_list):
         assert (affine_of(zk, cname, zk.point_add(cname, lo, hi)) == exp).all(), (cname, window_bits, "sharded")
     bases.free()
 
+def check_msm_window_groups(zk, cname, n, window_bits, groups=(1, 3, 5, 100)):
+    """zk_msm_opts.window_group: the windows of one job processed a few at a time (what a >= 2^21-point MSM does by itself so that
+    sorted entries + bases stay inside the Infinity Cache) -- every group size gives the same point, whole and as a window share"""
+    pts = bases_for(cname, n)
+    sc = scalars_for(cname, n, 47, realistic=True)
+    exp = orc.msm_ark(cname, pts, sc, threads=8)
+    bases = zk.Bases(cname, pts)
+    W = zk.msm_window_count(cname, n, window_bits)
+    for gw in groups:
+        got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=window_bits, window_group=gw))
+        assert (got == exp).all(), (cname, gw)
+        assert zk.msm_last_profile()["groups"] == -(-W // min(gw, W)), (cname, gw, zk.msm_last_profile()["groups"])
+        lo = zk.msm(bases, sc, window_bits=window_bits, windows=(0, W // 2), window_group=gw)
+        hi = zk.msm(bases, sc, window_bits=window_bits, windows=(W // 2, W), window_group=gw)
+        assert (affine_of(zk, cname, zk.point_add(cname, lo, hi)) == exp).all(), (cname, gw, "shares")
+    t = zk.msm_submit(bases, to_device(zk, sc), window_bits=window_bits, window_group=2)
+    assert (affine_of(zk, cname, t.collect()) == exp).all()
+    bases.free()
+
+
 def check_msm_slice_lengths(zk, cname, n, window_bits):
     """the bucket reduction for several slice lengths L (X_t = W_t + [t L] S_t with the 2-bit windowed multiplier):
     powers of two (the digits of t, then log2 L doublings), a non-power of two (digits of t L), L = all buckets"""
@@ -528,7 +548,12 @@ def check_multi_device(zk, ndev):
         adopted = zk.Bases(cname, device_tensor=to_device(zk, pts), n=n)      # resident on one device, copied to its peers
         assert (affine_of(zk, cname, zk.msm(adopted, sc, window_bits=wb)) == exp).all(), (cname, "adopted bases")
         adopted.free()
-    check_msm_batch(zk, "Vesta", 400, 3)
+    check_msm_batch(zk, "Vesta", 400, 3)          # >= one vector per device: whole MSMs per device, only those vectors travel
+    check_msm_batch(zk, "Pallas", 300, 7)         # an uneven split of the vectors
+    if ndev > 2:
+        check_msm_batch(zk, "Vesta", 260, 2)      # fewer vectors than devices: each one window-sharded over all devices
+    check_msm_async(zk, "Vesta", 300, 6)          # fanned-out tickets: a job per device behind each, collected out of order
+    check_ipa(zk, "Vesta", 4)                     # zk_ipa_round_device over the devices (the L / R pair), collapse, literal folds
     check_msm_edges(zk, "Bn254G1")
     check_ntt_vs_oracle(zk, "PallasFp", 9)
 

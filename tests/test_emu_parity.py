@@ -114,6 +114,11 @@ def test_msm_precomputed_table(zk):
     ps.check_msm_precomputed(zk, "Bn254G2", 256, 5)
 
 
+def test_msm_window_groups(zk):
+    ps.check_msm_window_groups(zk, "Vesta", 500, 6)
+    ps.check_msm_window_groups(zk, "Bls381G2", 60, 5, groups=(2, 7))
+
+
 def test_msm_axis_reduce(zk):
     ps.check_msm_axis_reduce(zk, "Vesta", 700, [2, 3, 4, 5, 8, 11])
     ps.check_msm_axis_reduce(zk, "Bn254G2", 300, [3, 6, 9])

@@ -157,6 +157,11 @@ def test_msm_precomputed_table(zk, cname, n, wb, count):
     ps.check_msm_precomputed(zk, cname, n, wb, realistic=(cname == "Bls381G1"), count=count)
 
 
+@pytest.mark.parametrize("cname,n,wb", [("Vesta", 1 << 15, 0), ("Bn254G1", 70000, 13), ("Bls381G2", 5000, 9)])
+def test_msm_window_groups(zk, cname, n, wb):
+    ps.check_msm_window_groups(zk, cname, n, wb)
+
+
 @pytest.mark.parametrize("cname,n,wbs", [("Vesta", 1 << 14, [2, 3, 4, 7, 10, 13, 15, 16]), ("Bls381G1", 1 << 13, [5, 12, 16]),
                                          ("Bn254G2", 1 << 12, [3, 9, 14, 16]), ("Bls381G2", 1 << 12, [8, 15, 16])])
 def test_msm_axis_reduce(zk, cname, n, wbs):
