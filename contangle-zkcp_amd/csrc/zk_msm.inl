@@ -448,12 +448,13 @@ int msm_enqueue_group(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typen
 // C: the curve of the ABI call.  CK: the view the kernels compute in.  bases: device array of StoredAffine<CK>.
 // Enqueues every kernel of the MSM and the copy of the per-window partial sums on job.stream and returns; no host
 // synchronisation (workspace growth aside).
-// Window groups: the windows of a large single MSM are processed a few at a time.  All windows at once keep n x windows sorted
-// entries (4 B each) plus the bases live while the accumulate kernel gathers -- 268 MB + 256 MB for 2^22 points x 16 windows,
-// past the 256 MiB Infinity Cache -- and the gathers then come from HBM; 4 windows at a time (64 MB of entries) were measured at
-// 1.82 ms against 8.68 / 4 = 2.17 ms (round 2, tools/shard_model.py BN254 2^22).  The groups are just window ranges of the
-// same job: each runs the whole pipeline over workspaces sized for a group, and the partial sums of all windows land in one
-// host buffer for the usual Horner.  Auto: groups of 2^24 / n windows from 2^21 points up; zk_msm_opts.window_group overrides.
+// Window groups (zk_msm_opts.window_group, OFF by default): the windows of a single MSM processed a few at a time, each group
+// running the whole pipeline over workspaces sized for a group, all partial sums landing in one host buffer.  The idea (round-2
+// shard model: 4 windows of a 2^22-point MSM in 1.82 ms against 8.68 / 4 = 2.17 ms) was that 16 windows keep 268 MB of sorted
+// entries + 256 MB of bases live, past the 256 MiB Infinity Cache.  Measured inside one job (profiles/r03_e_window_group_sweep.txt,
+// BN254 G1 2^22, ms: all 16 windows 8.20 | 2 groups 8.81 | 4 groups 8.81 | 8 groups 11.35): the accumulate kernels do get faster
+// (5.96 -> 5.62 in 4 groups) but every group pays its own sort launches and its own latency-bound bucket reduction, which costs
+// more than the cache gives back; with a 0/1-heavy witness it is 2.90 -> 3.95.  So the default is one group; the knob stays.
 template <class C, class CK>
 int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
     memset(&job.prof, 0, sizeof job.prof);
@@ -481,10 +482,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
     if (n == 0 || w1 <= w0) return ZK_OK;
     int gw = w1 - w0;                                  // windows per group
     if (job.batch == 1 && !tu.precomputed && !tu.device_partials) {
-        if (tu.window_group > 0)
-            gw = tu.window_group;
-        else if (n >= (1ull << 21))
-            gw = (int)((1ull << 24) / n);
+        if (tu.window_group > 0) gw = tu.window_group;
         if (gw < 1) gw = 1;
         if (gw > w1 - w0) gw = w1 - w0;
     }

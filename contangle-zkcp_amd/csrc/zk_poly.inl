@@ -418,9 +418,7 @@ int expr_compile29(const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, cons
         int rot = 0;
         uint32_t next = 0;
     } slots[EXPR29_SLOTS];
-    uint32_t nslots = EXPR29_SLOTS, hoist = 12;
-    if (const char* e = getenv("ZK_EXPR29_SLOTS")) nslots = (uint32_t)atoi(e) >= 1 && (uint32_t)atoi(e) <= EXPR29_SLOTS ? (uint32_t)atoi(e) : nslots;   // DIAGNOSTIC (temporary)
-    if (const char* e = getenv("ZK_EXPR29_HOIST")) hoist = (uint32_t)atoi(e);
+    const uint32_t nslots = EXPR29_SLOTS, hoist = 12;
     auto norm_top = [&]() {
         emit(EXPR29_NORM, 0, 0);
         st.back().lb = NP;

@@ -39,24 +39,29 @@ def _identity(curve):
 
 
 def _gather_add(curves, parts, group):
-    """parts: this rank's Jacobian partial sums, one per MSM (curves[i] names the curve of parts[i]); one all_gather of
-    the concatenation, then every rank adds the G partials of every MSM"""
+    """parts: this rank's Jacobian partial sums, one per MSM (curves[i] names the curve of parts[i]); ONE collective for the
+    concatenation -- over RCCL: one H2D of the (few hundred bytes of) partials, all_gather_into_tensor on the device, one D2H of
+    the gathered block -- then every rank adds the G partials of every MSM (zk_point_add: EC addition is not a reduction op)"""
     world, _ = _world(group)
     if world == 1:
         return parts
     flat = np.concatenate([np.ascontiguousarray(p, dtype=np.uint64).ravel() for p in parts])
     t = torch.from_numpy(flat.view(np.int64).copy())
     if dist.get_backend(group) == "nccl":
-        t = t.cuda()
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t, group=group)
-    host = [o.cpu().numpy().view(np.uint64) for o in outs]
+        dev = t.cuda()
+        out = torch.empty((world, dev.numel()), dtype=dev.dtype, device=dev.device)
+        dist.all_gather_into_tensor(out.view(-1), dev, group=group)
+        host = out.cpu().numpy().view(np.uint64)          # one copy of the whole block (synchronises)
+    else:
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t, group=group)
+        host = np.stack([o.numpy().view(np.uint64) for o in outs])
     res, off = [], 0
     for c, p in zip(curves, parts):
         ln = p.size
         acc = None
-        for h in host:
-            q = h[off:off + ln]
+        for r in range(world):
+            q = host[r, off:off + ln]
             acc = q.copy() if acc is None else point_add(c, acc, q)
         res.append(acc)
         off += ln

@@ -229,6 +229,50 @@ def _ptr_array(bufs):
     return (ctypes.c_void_p * len(bufs))(*[ctypes.cast(_ptr(b), ctypes.c_void_p).value for b in bufs])
 
 
+def permute_expression_pair(field, inputs_mont, table_mont, usable_rows):
+    """plonk/lookup/prover.rs permute_expression_pair -- a CPU step upstream (a sort and a BTreeMap) and here: host arrays of
+    Montgomery limbs [n, 4] in, (A', S') of usable_rows each out (the caller appends its blinding rows and uploads).  Values are
+    ordered as canonical integers (the field's Ord); raises ValueError where upstream returns ConstraintSystemFailure."""
+    p = field_modulus(field)
+    r_inv = pow(1 << 256, -1, p)
+
+    def canon(arr):            # Montgomery limbs -> canonical limbs, via Python integers (a host step; sizes are one column)
+        a = _np64(arr)[:usable_rows].astype(object)
+        v = (a[:, 0] + (a[:, 1] << 64) + (a[:, 2] << 128) + (a[:, 3] << 192)) * r_inv % p
+        return np.stack([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], axis=1).astype(np.uint64)
+
+    def to_mont(c):
+        a = c.astype(object)
+        v = ((a[:, 0] + (a[:, 1] << 64) + (a[:, 2] << 128) + (a[:, 3] << 192)) << 256) % p
+        return np.stack([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], axis=1).astype(np.uint64)
+
+    order = lambda c: np.lexsort((c[:, 0], c[:, 1], c[:, 2], c[:, 3]))     # most significant limb last = primary key
+    ci, ct = canon(inputs_mont), canon(table_mont)
+    a = ci[order(ci)]
+    t = ct[order(ct)]
+    first = np.ones(usable_rows, dtype=bool)
+    first[1:] = (a[1:] != a[:-1]).any(axis=1)
+    # the table's multiset: unique values and counts (t is sorted)
+    tb = np.ones(len(t), dtype=bool)
+    tb[1:] = (t[1:] != t[:-1]).any(axis=1)
+    tvals = t[tb]
+    tcnt = np.diff(np.append(np.flatnonzero(tb), len(t)))
+    key = lambda c: [tuple(int(x) for x in row[::-1]) for row in c]
+    index = {k: i for i, k in enumerate(key(tvals))}
+    for k in key(a[first]):
+        i = index.get(k)
+        if i is None or tcnt[i] == 0:
+            raise ValueError("ConstraintSystemFailure: a lookup input is not in the table")
+        tcnt[i] -= 1
+    s_perm = np.zeros((usable_rows, 4), dtype=np.uint64)
+    s_perm[first] = a[first]
+    leftovers = np.repeat(tvals, tcnt, axis=0)                     # ascending
+    repeated = np.flatnonzero(~first)
+    assert len(leftovers) == len(repeated)
+    s_perm[repeated[::-1]] = leftovers                              # upstream pops the repeated rows from the last one down
+    return to_mont(a), to_mont(s_perm)
+
+
 def batch_invert(field, a, stream=0):
     """arithmetic.rs BatchInvert on a device buffer, in place; zeros stay zero"""
     _check(_plib().zk_batch_invert_device(field_id(field), _ptr(a), int(a.shape[0]), ctypes.c_void_p(stream)), "zk_batch_invert_device")

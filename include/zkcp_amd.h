@@ -84,8 +84,8 @@ typedef struct {
     int waves_per_simd; /* accumulate-kernel waves launched per SIMD; 0 = what the kernel was compiled for */
     int flags;          /* ZK_MSM_FLAG_* */
     int base_offset;    /* use bases [base_offset, base_offset + n) of the handle (halo2's IPA works on halves of one generator vector) */
-    int window_group;   /* windows processed at a time by a large single MSM (sorted entries + bases should stay inside the 256 MiB Infinity
-                         * Cache); 0 = automatic: 2^24 / n windows from 2^21 points up, all at once below */
+    int window_group;   /* windows processed at a time by a single MSM (so that sorted entries + bases stay inside the 256 MiB Infinity Cache);
+                         * 0 = all at once, which measured faster at every size tried (profiles/r03_e_window_group_sweep.txt): A/B knob */
     int reserved;
 } zk_msm_opts;
 #define ZK_MSM_FLAG_NO_HOT_HELP 1   /* skewed witnesses: leave hot regions to their own sort workgroup */

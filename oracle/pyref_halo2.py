@@ -119,6 +119,33 @@ def multiopen_quotient(field, q_polys, point_sets, x_2, n):
     return acc
 
 
+def permute_expression_pair(field, inputs, table, usable_rows):
+    """plonk/lookup/prover.rs permute_expression_pair, the deterministic part (the blinding rows appended afterwards are the
+    caller's RNG): A' = the first usable_rows inputs sorted (the field's Ord = canonical integers); S': at the first
+    occurrence of every input value that value (one instance leaves the table's multiset; an input value that is not in the
+    table is an error), and the leftover table values, ascending, into the repeated-input rows taken from the LAST one down
+    (upstream pops them off a Vec)"""
+    a = sorted(inputs[:usable_rows])
+    left = {}
+    for v in table[:usable_rows]:
+        left[v] = left.get(v, 0) + 1
+    s_perm = [0] * usable_rows
+    repeated = []
+    for row, v in enumerate(a):
+        if row == 0 or v != a[row - 1]:
+            s_perm[row] = v
+            if left.get(v, 0) <= 0:
+                raise ValueError("ConstraintSystemFailure: input value not in the table")
+            left[v] -= 1
+        else:
+            repeated.append(row)
+    for v in sorted(left):
+        for _ in range(left[v]):
+            s_perm[repeated.pop()] = v
+    assert not repeated
+    return a, s_perm
+
+
 def eval_program(field, program, columns, consts, n_ext, rot_scale, i):
     """the quotient evaluator's stack program at row i of the extended domain (see include/zkcp_amd_prover.h, zk_expr_*):
     ops: ("col", column, rotation) ("const", index) ("add",) ("sub",) ("mul",) ("neg",) ("scale", index)"""

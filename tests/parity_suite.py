@@ -789,6 +789,32 @@ def check_permutation_and_lookup_products(zk, name, k, ncols=5, seed=9):
     assert last == 1
 
 
+def check_permute_expression_pair(zk, name, n=600, usable=590, seed=5):
+    """halo2 lookup argument, permute_expression_pair (a CPU step upstream and in the mirror): against the literal restatement,
+    then through zk_halo2_lookup_product_device -- for the permuted pair of a genuine lookup the grand product closes to 1"""
+    from oracle import pyref_halo2 as h2
+    p = pyref.FIELDS[name][0]
+    rng = pyref.Rng(seed)
+    table = [rng.below(p) for _ in range(40)] + [3, 3, 7]
+    table = (table * (usable // len(table) + 1))[:usable]
+    inputs = [table[rng.below(len(table))] for _ in range(usable)]
+    pad = lambda v: v + [rng.below(p) for _ in range(n - usable)]
+    a_exp, s_exp = h2.permute_expression_pair(name, inputs, table, usable)
+    a_got, s_got = zk.halo2.permute_expression_pair(name, _monts(name, pad(list(inputs))), _monts(name, pad(list(table))), usable)
+    assert (a_got == _monts(name, a_exp)).all() and (s_got == _monts(name, s_exp)).all(), name
+    assert sorted(s_exp) == sorted(table) and all(a_exp[i] == s_exp[i] or a_exp[i] == a_exp[i - 1] for i in range(usable))
+    beta, gamma = rng.below(p), rng.below(p)
+    z_out = to_device(zk, np.zeros((usable, 4), dtype=np.uint64))
+    last = zk.halo2.lookup_product(name, to_device(zk, _monts(name, inputs)), to_device(zk, _monts(name, table)), to_device(zk, a_got), to_device(zk, s_got),
+                                   _monts(name, [beta])[0], _monts(name, [gamma])[0], z_out)
+    assert (last == _monts(name, [1])[0]).all(), "the lookup product of a permuted pair closes to 1"
+    try:
+        zk.halo2.permute_expression_pair(name, _monts(name, [5, 6] + inputs[2:]), _monts(name, table), usable)
+        raise AssertionError("an input outside the table must be refused")
+    except ValueError:
+        pass
+
+
 def check_eval_polynomial(zk, name, sizes=(1, 2, 15, 16, 17, 1000, 4099), seed=77):
     """halo2 arithmetic.rs eval_polynomial on the device against Python integers (Horner); edge points 0, 1, p - 1"""
     p = pyref.FIELDS[name][0]

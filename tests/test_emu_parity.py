@@ -185,6 +185,11 @@ def test_halo2_products(zk):
     ps.check_permutation_and_lookup_products(zk, "PallasFp", 6)
 
 
+def test_halo2_permute_expression_pair(zk):
+    ps.check_permute_expression_pair(zk, "PallasFp")
+    ps.check_permute_expression_pair(zk, "Bls381Fr", n=90, usable=83)
+
+
 def test_halo2_ipa_collapse_edges(zk):
     ps.check_ipa_collapse_edges(zk, "Vesta", 5)
 

@@ -509,6 +509,10 @@ def test_halo2_permutation_and_lookup_products(zk, name, k):
     ps.check_permutation_and_lookup_products(zk, name, k)
 
 
+def test_halo2_permute_expression_pair(zk):
+    ps.check_permute_expression_pair(zk, "PallasFp", n=5000, usable=4990)
+
+
 @pytest.mark.parametrize("cname,k", [("Vesta", 8), ("Pallas", 12)])
 def test_halo2_ipa_collapse_edges(zk, cname, k):
     ps.check_ipa_collapse_edges(zk, cname, k)
