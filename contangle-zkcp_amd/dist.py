@@ -119,13 +119,41 @@ def msm_sharded(bases, scalars, montgomery=False, window_bits=0, group=None, str
     return _gather_add([bases.curve], [part], group)[0]
 
 
+def _gather_blocks(blocks, counts, width, group):
+    """rank r contributes blocks [counts[r], width] (its whole results); every rank gets all of them in rank order -- one collective"""
+    world, rank = _world(group)
+    cap = max(counts)
+    mine = np.zeros((cap, width), dtype=np.uint64)
+    mine[:counts[rank]] = blocks
+    t = torch.from_numpy(mine.view(np.int64).copy())
+    if dist.get_backend(group) == "nccl":
+        dev = t.cuda()
+        out = torch.empty((world,) + tuple(dev.shape), dtype=dev.dtype, device=dev.device)
+        dist.all_gather_into_tensor(out.view(-1), dev.view(-1), group=group)
+        host = out.cpu().numpy().view(np.uint64)
+    else:
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t, group=group)
+        host = np.stack([o.numpy().view(np.uint64) for o in outs])
+    return np.concatenate([host[r, :counts[r]] for r in range(world)])
+
+
 def msm_batch_sharded(bases, d_cols, montgomery=False, window_bits=0, group=None, stream=0):
     """count MSMs over the same bases (d_cols: device buffer [count, n, 4]); returns [count, 3 * limbs] on every rank.
-    One batched device call per rank and one all_gather for all columns."""
+    With at least one vector per rank every rank computes the WHOLE MSMs of its share of the vectors -- the fixed costs of an
+    MSM (digit extraction over all 16 windows, sort launches, the latency-bound reduction, the host tail) are then paid once
+    per vector, not once per vector and rank, and nothing has to be added afterwards -- and one all_gather hands the results
+    round.  Fewer vectors than ranks (the three permutation products on 4 or 8 GPUs): each vector by scalar-window range
+    (SURVEY 8e), one batched device call per rank and ONE all_gather of the partial sums for all of them."""
     world, rank = _world(group)
     count, n = int(d_cols.shape[0]), int(d_cols.shape[1])
     if world == 1 or n < SHARD_MIN_POINTS:
         return msm_batch(bases, d_cols, montgomery=montgomery, window_bits=window_bits, stream=stream)
+    if count >= world:
+        bounds = [count * r // world for r in range(world + 1)]
+        lo, hi = bounds[rank], bounds[rank + 1]
+        mine = msm_batch(bases, d_cols[lo:hi], montgomery=montgomery, window_bits=window_bits, stream=stream)
+        return _gather_blocks(np.asarray(mine), [bounds[r + 1] - bounds[r] for r in range(world)], 3 * base_limbs(bases.curve), group)
     lo, hi = window_range(msm_window_count(bases.curve, n, window_bits), rank, world)
     if hi > lo:
         parts = msm_batch(bases, d_cols, montgomery=montgomery, window_bits=window_bits, windows=(lo, hi), stream=stream)

@@ -116,13 +116,17 @@ def check_msm_golden(zk):
             n = case["n"]
             pts, sc, exp = golden_msm_case(cname, case)
             bases = zk.Bases(cname, pts)
-            for wb in ((0, 3, 7) if not zk.backend_info().startswith("emu") else (0, 6)):   # the CPU emulator pays per launched lane
+            emu = zk.backend_info().startswith("emu")
+            if emu and n > 33 and pyref.is_g2(cname):
+                continue                                                    # (the emulator pays per launched lane: the GPU tier runs every case)
+            for wb in ((0, 3, 7) if not emu else ((0, 6) if n <= 5 else (0,))):
                 got = affine_of(zk, cname, zk.msm(bases, sc, window_bits=wb))
                 assert (got == exp).all(), (cname, n, wb)
-            got = affine_of(zk, cname, zk.ark.VariableBaseMSM.multi_scalar_mul(bases, sc))
-            assert (got == exp).all()
-            got = affine_of(zk, cname, zk.halo2.best_multiexp(orc.to_mont(sf, sc), bases))
-            assert (got == exp).all(), (cname, n, "halo2")
+            if not emu or n <= 5:
+                got = affine_of(zk, cname, zk.ark.VariableBaseMSM.multi_scalar_mul(bases, sc))
+                assert (got == exp).all()
+                got = affine_of(zk, cname, zk.halo2.best_multiexp(orc.to_mont(sf, sc), bases))
+                assert (got == exp).all(), (cname, n, "halo2")
             bases.free()
 
 
@@ -532,13 +536,16 @@ def check_multi_device(zk, ndev):
     the partial sums are added on the host; host-pointer and device-pointer entries, more devices than windows, an
     explicit window range (stays on the home device), batches and deferred results on a multi-device process"""
     assert zk.device_count() == ndev
-    for cname, n, wb in (("Vesta", 700, 0), ("Bls381G1", 300, 7), ("Bn254G2", 90, 5), ("Pallas", 50, 13)):
+    for ci, (cname, n, wb) in enumerate((("Vesta", 500, 0), ("Bls381G1", 200, 7), ("Bn254G2", 60, 5), ("Pallas", 50, 13))):
         pts = bases_for(cname, n)
         sc = scalars_for(cname, n, 71, realistic=True)
         exp = orc.msm_ark(cname, pts, sc, threads=8)
         bases = zk.Bases(cname, pts)
         assert (affine_of(zk, cname, zk.msm(bases, sc, window_bits=wb)) == exp).all(), (cname, "host scalars")
         assert (affine_of(zk, cname, zk.msm(bases, to_device(zk, sc), window_bits=wb)) == exp).all(), (cname, "device scalars")
+        if ci in (1, 2) and ndev == 2:
+            bases.free()
+            continue                                   # (CPU-emulator time: the 3-device case runs every form on every curve)
         W = zk.msm_window_count(cname, n, wb)
         lo = zk.msm(bases, sc, window_bits=wb, windows=(0, W // 2))
         hi = zk.msm(bases, sc, window_bits=wb, windows=(W // 2, W))
@@ -548,13 +555,14 @@ def check_multi_device(zk, ndev):
         adopted = zk.Bases(cname, device_tensor=to_device(zk, pts), n=n)      # resident on one device, copied to its peers
         assert (affine_of(zk, cname, zk.msm(adopted, sc, window_bits=wb)) == exp).all(), (cname, "adopted bases")
         adopted.free()
-    check_msm_batch(zk, "Vesta", 400, 3)          # >= one vector per device: whole MSMs per device, only those vectors travel
-    check_msm_batch(zk, "Pallas", 300, 7)         # an uneven split of the vectors
+    check_msm_batch(zk, "Vesta", 200, 3)          # >= one vector per device: whole MSMs per device, only those vectors travel
     if ndev > 2:
-        check_msm_batch(zk, "Vesta", 260, 2)      # fewer vectors than devices: each one window-sharded over all devices
-    check_msm_async(zk, "Vesta", 300, 6)          # fanned-out tickets: a job per device behind each, collected out of order
-    check_ipa(zk, "Vesta", 4)                     # zk_ipa_round_device over the devices (the L / R pair), collapse, literal folds
-    check_msm_edges(zk, "Bn254G1")
+        check_msm_batch(zk, "Pallas", 120, 7, 6)  # an uneven split of the vectors
+        check_msm_batch(zk, "Vesta", 130, 2, 6)   # fewer vectors than devices: each one window-sharded over all devices
+        check_ipa(zk, "Vesta", 3)                 # zk_ipa_round_device over the devices (the L / R pair), collapse, literal folds
+    else:
+        check_msm_async(zk, "Vesta", 150, 6)      # fanned-out tickets: a job per device behind each, collected out of order
+        check_msm_edges(zk, "Bn254G1")
     check_ntt_vs_oracle(zk, "PallasFp", 9)
 
 

@@ -46,9 +46,12 @@ def _worker(rank, world, port, emu_path, q):
         ok &= bool((zk.point_to_affine(cname, full) == exp).all())
         # the batched form (halo2's column commitments): one device call and ONE all_gather for all columns
         cols = np.stack([sc, ps.scalars_for(cname, n, 32), ps.scalars_for(cname, n, 33, realistic=True)])
-        got = zkdist.msm_batch_sharded(bases, ps.to_device(zk, cols), window_bits=wb)
+        got = zkdist.msm_batch_sharded(bases, ps.to_device(zk, cols), window_bits=wb)      # 3 vectors >= world: whole MSMs per rank
         for i in range(3):
             ok &= bool((zk.point_to_affine(cname, got[i]) == orc.msm_ark(cname, pts, cols[i], threads=2)).all())
+        got2 = zkdist.msm_batch_sharded(bases, ps.to_device(zk, cols[:world - 1]), window_bits=wb)   # fewer vectors than ranks: window shares
+        for i in range(world - 1):
+            ok &= bool((zk.point_to_affine(cname, got2[i]) == orc.msm_ark(cname, pts, cols[i], threads=2)).all())
         # several MSMs over different bases (Groth16's five), submitted together, one all_gather
         pts2 = ps.bases_for(cname, n, seed=12)
         bases2 = zk.Bases(cname, pts2)
