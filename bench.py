@@ -22,6 +22,8 @@ Launch: `python bench.py [--gpus 1 --steps K --warmup W]`, or for N > 1
 Inputs come from contangle-zkcp_amd/synth.py; only the cpu_baseline leg touches oracle/.
 """
 import argparse
+import concurrent.futures
+import gc
 import hashlib
 import json
 import os
@@ -113,6 +115,12 @@ def setup():
                          "(zk_ipa_collapse_device) and continues over them; 'fold' collapses the generator vector every round as upstream "
                          "does (one scalar multiplication per surviving point)")
     ap.add_argument("--ipa-collapse-after", default="6", help="round count(s) after which the generators are materialised, e.g. 6 or 6,10")
+    ap.add_argument("--quotient-parts", type=int, default=1, choices=[1, 2, 4, 8],
+                    help="halo2 work-list: the extended coset handled as this many sub-cosets -- expression, division and an inverse transform of "
+                         "size 2^23 / parts per sub-coset, whose folded coefficients are committed while the next sub-coset is evaluated; the "
+                         "pieces' commitments are combinations of those (commitments are linear).  1 (default on one GPU) = upstream's order: one "
+                         "expression pass, extended_to_coeff, then the 8 commitments -- measured faster there (the GPU is issue-bound either way: "
+                         "profiles/r03_j_*); N > 1 ranks always use 8, dealt round-robin: that is how the quotient and its commitments shard")
     ap.add_argument("--precomputed", action="store_true",
                     help="single-GPU A/B: the MSMs use ONE bucket set over a table of window multiples of the bases (zk_bases_precompute, 16 x the "
                          "key in HBM) instead of one bucket set per window")
@@ -183,6 +191,8 @@ def timed(e, step):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
     for i in range(e.args.warmup):
         step(i, False)
+    gc.collect()       # the set-up's garbage (host copies of the columns) is collected here, not at some point inside a timed step
+    gc.freeze()
     barrier(e)
     e.zk.msm_profile_totals(reset=True)
     e.zk.ntt_profile_enable(True)
@@ -293,9 +303,14 @@ def bench_halo2(e):
       9 opening       the inner-product argument on p: commit the blinding polynomial s ; p' = s xi + p ; p'(x_3) ; b = powers of
                       x_3 ; k rounds of 2 MSMs + 2 inner products + 3 folds
     A chain keeps BOTH forms of its column: the coefficients (out of place, for steps 7-8) and the extended coset.
-    N > 1 ranks (one process per GPU): every MSM of 2^17 points or more is window-range sharded; the extended coset is split
-    into N sub-cosets (rank j: the points ZETA w_ext^(iN + j)) so that the coset transforms, the expression and the division
-    by the vanishing polynomial are sharded with no exchange, then ONE all_gather of h (32 B per extended row)."""
+    With --quotient-parts P > 1 (always 8 on N > 1 ranks) the quotient (step 6) runs sub-coset by sub-coset: each sub-coset's numerator is divided, brought to
+    its folded coefficients by ONE transform of size 2^23 / parts, and committed slice by slice while the next sub-coset is being
+    evaluated; the 8 pieces' commitments are fixed linear combinations of the slices' commitments (EvaluationDomain.piece_scalars) and
+    the folded h(X) of step 7 a linear combination of the slices -- the same group elements / field elements as upstream's order
+    (tests: check_quotient_by_parts), which --quotient-parts 1 runs for comparison.
+    N > 1 ranks (one process per GPU): every column MSM of 2^17 points or more is window-range sharded (batches by vector); the 8
+    sub-cosets are dealt round-robin, so coset transforms, expression, division, inverse transforms AND the quotient's MSMs are
+    sharded with no exchange but one all_gather of the slices' commitments and one of a folded vector (32 B per row) per rank."""
     a, zk, torch, np = e.args, e.zk, e.torch, e.np
     H = zk.halo2
     curve = a.curve if a.curve in ("Vesta", "Pallas") else "Vesta"
@@ -306,9 +321,12 @@ def bench_halo2(e):
     g_coeff, d_pts_c = make_bases(e, curve, n, 0x5EEE)          # Params::g (coefficient basis): h pieces, random polys, q', IPA
     dom = H.EvaluationDomain(sfield, 9, k)             # degree-9 gates -> extended_k = k + 3 (Orchard-style)
     assert dom.extended_k == ext
-    parts = e.world if e.world in (1, 2, 4, 8) else 1       # sub-cosets of the extended domain, one per rank
-    part = e.rank if parts > 1 else 0
-    m, rsc = ne // parts, dom.rot_scale_part(parts)
+    # sub-cosets of the extended domain (dom.coeff_to_extended_part): QP in all, this rank's are my_parts (round-robin over the ranks)
+    QP = 8 if e.world > 1 else a.quotient_parts
+    my_parts = [j for j in range(QP) if j % e.world == e.rank]
+    PL = len(my_parts)
+    m, rsc = ne // QP, dom.rot_scale_part(QP)
+    r_sl = m // n                                           # n-coefficient slices (= quotient pieces' worth) per sub-coset
     rf = lambda seed, cnt=n: e.synth.rand_field(sfield, cnt, seed)
     newbuf = lambda *shape: torch.empty(shape + (4,), dtype=torch.int64, device="cuda")
     # ---- inputs: Lagrange columns (instance 0..2, advice 3..15: one buffer, one batched commitment), lookup columns, challenges
@@ -317,7 +335,12 @@ def bench_halo2(e):
     d_lag = to_dev(e, lag_host)
     d_lookup = to_dev(e, np.stack([rf(0xA0), rf(0xA1), rf(0xA2), rf(0xA3)]))     # A, S and the permuted A', S' (the sort is upstream's CPU step)
     d_sigma = [to_dev(e, rf(0x51 + c)) for c in range(N_PERM_COLS)]              # permutation polynomials (Lagrange): key material
-    d_fixed_cos = [to_dev(e, rf(0xF1 + c + 64 * part, m)) for c in range(N_FIXED)]   # fixed columns on this rank's sub-coset: key material
+    # fixed columns on this rank's sub-cosets: key material (one seeded extended vector per column, so that every split of the coset sees the same column)
+    d_fixed_cos = []
+    for c in range(N_FIXED):
+        full = rf(0xF1 + c, ne)
+        d_fixed_cos.append(to_dev(e, np.stack([full[j::QP] for j in my_parts])))
+    del full
     beta, gamma, delta, y = (rf(0xC1, 1)[0], rf(0xC2, 1)[0], rf(0xC3, 1)[0], rf(0xC4, 1)[0])
     x, x1, x2, x3, x4, xi = (rf(0xE0 + j, 1)[0] for j in range(6))
     us = [rf(0xD0 + j, 1)[0] for j in range(k)]                                   # IPA challenges
@@ -350,11 +373,12 @@ def bench_halo2(e):
     d_spoly = to_dev(e, rf(0xBB5))                                                # the argument's blinding polynomial s (RNG: CPU)
     # ---- chains: every committed Lagrange column -> coefficients (kept) -> this rank's sub-coset of the extended domain
     chain_names = [("inst", c) for c in range(N_INST)] + [("adv", c) for c in range(NCOL)] + [("lk", "A'"), ("lk", "S'"), ("lk", "Z")] + [("zp", c) for c in range(3)]
-    d_cos = {nm: newbuf(m) for nm in chain_names}
+    d_cos = {nm: newbuf(PL, m) for nm in chain_names}
     d_zl = newbuf(n)
     d_zp = newbuf(3, n)
-    d_hpart = newbuf(m)
-    d_h = d_hpart if parts == 1 else newbuf(ne)
+    d_hp = newbuf(PL, m)                       # the quotient's numerator on this rank's sub-cosets, then their folded coefficients
+    hp_flat = d_hp.view(PL * r_sl, n, 4)       # ... as n-coefficient slices: what gets committed
+    d_hsum = newbuf(e.world, n) if e.world > 1 else None
     d_q = newbuf(len(sets), n)           # the point sets' folded polynomials
     d_qprime, d_tmp = newbuf(n), newbuf(n)
     d_ipa = [newbuf(n) for _ in range(2)]
@@ -363,9 +387,12 @@ def bench_halo2(e):
     lazy_expr = a.expr_limbs != 32
     if lazy_expr:                                     # key material in the evaluator's radix, once
         for d in d_fixed_cos:
-            H.to_lazy_form(sfield, d, stream=e.st)
+            H.to_lazy_form(sfield, d.view(PL * m, 4), stream=e.st)
     main = torch.cuda.current_stream()
     side = main if a.serial else torch.cuda.Stream()
+    msm_stream = side       # the quotient's slice commitments, issued from a worker thread: the chains' stream is idle by then (one more
+                            # stream would shift every stream's hardware queue: measured +6 ms per step with an unused extra stream)
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     ev_zp, ev_zl = torch.cuda.Event(), torch.cuda.Event()
     result = {}
     PH = ("advice", "lookup", "permutation", "quotient", "evaluations", "multiopen", "opening")
@@ -377,7 +404,11 @@ def bench_halo2(e):
         """Lagrange column -> coefficients (out of place, kept for the openings) -> this rank's sub-coset"""
         co = d_coef[row[nm]]
         dom.lagrange_to_coeff(src, stream=stream, out=co)
-        dom.coeff_to_extended_part(co, d_cos[nm], part, parts, stream=stream, lazy_out=lazy_expr)
+        if e.world == 1:      # every sub-coset is this rank's: ONE transform of the whole coset, stored sub-coset by sub-coset
+            dom.coeff_to_extended(d_cos[nm].view(ne, 4), stream=stream, coeffs=co, lazy_out=lazy_expr, parts=QP)
+        else:                 # a rank's own sub-cosets: one transform of size 2^23 / 8 each
+            for jj, j in enumerate(my_parts):
+                dom.coeff_to_extended_part(co, d_cos[nm][jj], j, QP, stream=stream, lazy_out=lazy_expr)
 
     collapse_at = {int(v) for v in str(a.ipa_collapse_after).split(",") if v.strip()}
     pre = a.precomputed and e.world == 1
@@ -448,18 +479,74 @@ def bench_halo2(e):
         # ---- 5 vanishing argument's random polynomial, 6 quotient
         commit(g_coeff, d_coef[row[("random", 0)]])
         main.wait_stream(side)                                      # every coset (and coefficient form) is complete from here on
-        ext_cols = ([d_cos[("adv", c)] for c in range(NCOL)] + d_fixed_cos + [d_cos[("lk", "A'")], d_cos[("lk", "S'")], d_cos[("lk", "Z")]]
-                    + [d_cos[("zp", c)] for c in range(3)] + [d_cos[("inst", c)] for c in range(N_INST)])
-        H.evaluate_expression(sfield, prog, ext_cols, consts, ext - (parts.bit_length() - 1), rsc, d_hpart, stream=e.st, lazy=lazy_expr)
-        dom.divide_by_vanishing_poly_part(d_hpart, part, parts, stream=e.st)
-        if parts > 1:
-            e.zkdist.gather_parts(d_hpart, d_h, stream=main)
-        dom.extended_to_coeff(d_h, stream=e.st)
-        pieces = d_h.view(N_H_PIECES, n, 4)
-        commit_batch(g_coeff, pieces)
+        xn_int = to_int(xn)
+        cols_of = lambda jj: ([d_cos[("adv", c)][jj] for c in range(NCOL)] + [d[jj] for d in d_fixed_cos]
+                              + [d_cos[("lk", "A'")][jj], d_cos[("lk", "S'")][jj], d_cos[("lk", "Z")][jj]]
+                              + [d_cos[("zp", c)][jj] for c in range(3)] + [d_cos[("inst", c)][jj] for c in range(N_INST)])
+        if QP == 1:
+            # upstream's order: the whole extended coset at once, extended_to_coeff, then the 8 pieces' commitments
+            H.evaluate_expression(sfield, prog, cols_of(0), consts, ext, rsc, d_hp[0], stream=e.st, lazy=lazy_expr)
+            dom.divide_by_vanishing_poly_part(d_hp[0], 0, 1, stream=e.st)
+            dom.extended_to_coeff(d_hp[0], stream=e.st)
+            result["h_commitments"] = commit_batch(g_coeff, hp_flat)
+            H.vec_fold_many(sfield, d_coef[row[("h", 0)]], hp_flat, xn, stream=e.st, reverse=True)
+        else:
+            # Sub-coset by sub-coset: numerator, division by its one vanishing value, inverse transform of size m -> the folded
+            # coefficients A_j (EvaluationDomain.part_to_coeff).  Their n-coefficient slices are committed in batches of 4 from a worker
+            # thread on its own stream WHILE the next sub-cosets are evaluated here: upstream's chain expression -> extended_to_coeff ->
+            # 8 MSMs has nothing to overlap, this one hides the expression behind the MSMs.  The pieces' commitments and the folded h(X)
+            # the evaluation phase needs are fixed linear combinations of the slices' commitments / of the slices.
+            futs, launched = [], 0
+            for jj, j in enumerate(my_parts):
+                H.evaluate_expression(sfield, prog, cols_of(jj), consts, ext - (QP.bit_length() - 1), rsc, d_hp[jj], stream=e.st, lazy=lazy_expr)
+                dom.divide_by_vanishing_poly_part(d_hp[jj], j, QP, stream=e.st)
+                dom.part_to_coeff(d_hp[jj], j, QP, stream=e.st)
+                ready = (jj + 1) * r_sl
+                while ready - launched >= 4 or (jj + 1 == PL and launched < ready):
+                    hi = min(launched + 4, ready)
+                    if a.serial:
+                        futs.append(zk.msm_batch(g_coeff, hp_flat[launched:hi], montgomery=True, window_bits=a.window_bits, stream=e.st))
+                    else:
+                        ev_q = torch.cuda.Event()
+                        ev_q.record(main)
+                        msm_stream.wait_event(ev_q)
+                        futs.append(pool.submit(zk.msm_batch, g_coeff, hp_flat[launched:hi], montgomery=True, window_bits=a.window_bits,
+                                                stream=msm_stream.cuda_stream))
+                    launched = hi
+            # the folded quotient: sum over this rank's slices of e[j][s] * A_j[slice s] (then over the ranks)
+            e_js = dom.fold_scalars(QP, xn_int)
+            dst = d_coef[row[("h", 0)]] if e.world == 1 else d_hsum[e.rank]
+            for jj, j in enumerate(my_parts):
+                for s_ in range(r_sl):
+                    if jj == 0 and s_ == 0:
+                        dst.copy_(hp_flat[0])
+                        zk.vec_op(sfield, "scale", dst, scalar=mont(e_js[j][0]), stream=e.st)
+                    else:
+                        H.vec_muladd(sfield, hp_flat[jj * r_sl + s_], dst, mont(e_js[j][s_]), stream=e.st, out=dst)
+            C_loc = np.concatenate([f if a.serial else f.result() for f in futs])
+            if not a.serial:
+                main.wait_stream(msm_stream)
+            if e.world > 1:
+                max_rows = -(-QP // e.world) * r_sl                 # (an uneven deal -- 3, 5, 6, 7 ranks -- is padded)
+                C_all, order = e.zkdist.gather_rows(C_loc, max_rows), {}
+                for rk in range(e.world):
+                    for jj, j in enumerate(jx for jx in range(QP) if jx % e.world == rk):
+                        for s_ in range(r_sl):
+                            order[(j, s_)] = rk * max_rows + jj * r_sl + s_
+                e.zkdist.gather_stack(d_hsum[e.rank], d_hsum)
+                hsum = d_coef[row[("h", 0)]]
+                hsum.copy_(d_hsum[0])
+                for rk in range(1, e.world):
+                    zk.vec_op(sfield, "add", hsum, d_hsum[rk], stream=e.st)
+            else:
+                C_all, order = C_loc, {(j, s_): j * r_sl + s_ for j in range(QP) for s_ in range(r_sl)}
+            rows_q = dom.piece_scalars(QP)
+            used = sorted(order.values())                                # (padding rows of an uneven deal are not points)
+            C_all, order = C_all[used], {kk: used.index(v) for kk, v in order.items()}
+            result["h_commitments"] = H.combine_commitments(curve, C_all, [[(order[(j, s_)], sc) for j, s_, sc in terms] for _, terms in rows_q],
+                                                            to_device=lambda arr: to_dev(e, arr), stream=e.st)
         t5 = time.perf_counter()
         # ---- 7 evaluations: h(X) = sum_i x^(n i) h_i, then every committed polynomial at x and at its rotations
-        H.vec_fold_many(sfield, d_coef[row[("h", 0)]], pieces, xn, stream=e.st, reverse=True)
         result["evals"] = [H.eval_polynomials(sfield, d_coef, x, stream=e.st),
                            H.eval_polynomials(sfield, d_coef[sets[1][0]:], x_next, stream=e.st),
                            H.eval_polynomials(sfield, d_coef[sets[2][0]:sets[2][0] + sets[2][1]], x_prev, stream=e.st),
@@ -534,21 +621,27 @@ def bench_halo2(e):
         line = base_line(e, n * a.steps / elapsed, elapsed,
                          "halo2 create_proof device work-list, 2^%d rows, the reference circuit's column layout (BASELINE configs[2]): %d instance + %d advice commits "
                          "(Lagrange basis) + %d NTT chains (l2c kept + coeff_to_extended) ; lookup: 2 + 1 commits, product ; permutation: 3 products + 3 commits ; "
-                         "random-poly commit ; quotient: %d-op expression over %d extended columns, divide by Z_H, extended_to_coeff, %d h-piece commits ; "
+                         "random-poly commit ; quotient: %d-op expression over %d extended columns, divide by Z_H, %s, %d h-piece commitments ; "
                          "%d evaluations at 4 points ; multiopen: 4 point sets (x_1 folds, %d kate divisions, x_2 fold, q' commit, evaluations at x_3, x_4 fold) ; "
                          "%d-round IPA on p (s commit, p' = s xi + p, b = powers of x_3 ; 2 MSMs + 2 inner products + 3 folds per round; generators %s)" % (
-                             k, N_INST, NCOL, n_chain, len(prog), NCOL + N_FIXED + 6 + N_INST, N_H_PIECES, n_eval, n_kate, k,
+                             k, N_INST, NCOL, n_chain, len(prog), NCOL + N_FIXED + 6 + N_INST,
+                             "extended_to_coeff" if QP == 1 else "per sub-coset (%d): inverse transform of size 2^%d, its %d slice commitment(s) issued beside the next "
+                             "sub-coset's expression; pieces = linear combinations" % (QP, ext - (QP.bit_length() - 1), r_sl), N_H_PIECES, n_eval, n_kate, k,
                              {"fold": "folded every round", "virtual": "never folded: every MSM over the SRS",
                               "collapse": "materialised after round(s) %s by zk_ipa_collapse_device" % a.ipa_collapse_after}[a.ipa]),
                          {"rows_per_step": n, "msm_curve": curve, "msm_points": n, "msm_windows_done": prof["windows_done"], "msm_windows": prof["windows_total"],
                           "window_bits": prof["window_bits"], "columns": NCOL, "instance_columns": N_INST, "full_size_msms_per_step": n_commit,
-                          "ntt_2p%d_per_step" % k: n_chain, "ntt_2p%d_per_step" % ext: n_chain + 1, "kate_divisions_per_step": n_kate, "evaluations_per_step": n_eval,
-                          "extended_coset_parts": parts,
+                          "ntt_2p%d_per_step" % k: n_chain, "ntt_2p%d_per_step" % (ext - (QP.bit_length() - 1)): (n_chain + 1) * QP, "kate_divisions_per_step": n_kate, "evaluations_per_step": n_eval,
+                          "extended_coset_parts": QP,
                           "streams": "one (serial)" if a.serial else "MSM batches on two library streams + NTT chains on a third",
                           "not_in_list": "RNG (blinding, random polynomials), transcript, the lookup argument's sort (CPU)"})
         if e.world > 1:
-            line["config"]["parallelism"] = "msm-window-shard x%d + all_gather ; extended coset in %d sub-cosets + all_gather of h" % (e.world, parts)
+            line["config"]["parallelism"] = ("msm-window-shard x%d + all_gather ; extended coset in %d sub-cosets dealt round-robin: expression, inverse transform and "
+                                             "slice commitments per rank, all_gather of %d commitments + one folded vector per rank" % (e.world, QP, QP * r_sl))
         line["phases_ms"] = {kk: v / a.steps for kk, v in phase_ms.items()}
+        # the same proof elements whatever the order of work / number of ranks: a digest to compare runs by
+        line["digest"] = {"h_commitments": hashlib.sha256(b"".join(zk.point_to_affine(curve, c_).tobytes() for c_ in result["h_commitments"])).hexdigest()[:16],
+                          "evals_at_x": hashlib.sha256(result["evals"][0].tobytes()).hexdigest()[:16]}
         line["msms_per_step"] = mm["msms"] / a.steps
         by_class = {}
         for name, cs in cls_sum.items():

@@ -13,10 +13,16 @@ using namespace zk;
 
 namespace zk {
 Ctx g;
-int msm_pick_c(uint64_t n, int requested) {
-    if (requested > 0) return requested < 2 ? 2 : (requested > 16 ? 16 : requested);  // digits are stored as u16 codes
+int msm_pick_c(uint64_t n, int requested, bool pre) {
+    // digits are stored as u16 codes; the precomputed-table form (one bucket set, 32-bit codes) goes up to 2^19 buckets
+    const int cmax = pre ? 20 : 16;
+    if (requested > 0) return requested < 2 ? 2 : (requested > cmax ? cmax : requested);
     int l = 0;
     while ((1ull << l) < n) l++;
+    // one bucket set over the table of window multiples: the windows no longer pay a bucket reduction each, so the window can
+    // grow until the ONE reduction (2^(c-1) buckets) costs what the 16 x 2^15 of the plain form do -- 13 windows instead of 16
+    // at 2^20 points (tools/r3_pre.sh: measured)
+    if (pre && l >= 17) return l >= 20 ? 20 : l;
     // Measured on one MI355X (profiles/r02_g_msm_size_sweep_vesta.txt): below 2^20 points the fixed costs decide -- the bucket
     // reduction's dependent additions, the host Horner (c doublings per window), the sort launches -- not the additions per
     // point, so the rule "2^5 points per bucket" (c = log2 n - 4) of round 1 was 20 - 45 % slow from 2^15 to 2^19.
@@ -365,7 +371,7 @@ int msm_fanout(zk_curve_t c, const BasesEntry& be, const void* src, DeviceCtx* s
                const MsmTuning& tu_in, void* out) {
     const int G = (int)g.devs.size();
     int nwin = 0;
-    CURVE_SWITCH(c, nwin = msm_windows<C>(msm_pick_c(n, tu_in.window_bits)));
+    CURVE_SWITCH(c, nwin = msm_windows<C>(msm_pick_c(n, tu_in.window_bits, tu_in.precomputed)));
     const size_t pbytes = jac_bytes(c);
     std::vector<std::vector<unsigned char>> parts(G, std::vector<unsigned char>(pbytes));
     hipEvent_t ready = nullptr;
@@ -664,7 +670,7 @@ API int zk_bases_precompute(uint64_t handle, int window_bits) {
     if (it == g.bases.end()) return ZK_ERR_BAD_HANDLE;
     BasesEntry& be = it->second;
     const zk_curve_t c = (zk_curve_t)be.curve;
-    const int cw = msm_pick_c(be.n, window_bits);
+    const int cw = msm_pick_c(be.n, window_bits, true);
     for (size_t d = 0; d < be.per_dev.size(); d++) {
         ZK_TRY(bind_device(*g.devs[d]));
         int st = ZK_ERR_INVALID_ARG;
@@ -722,7 +728,7 @@ API int zk_msm_submit(zk_curve_t c, uint64_t handle, const void* d_scalars, uint
         const int G = (int)g.devs.size();
         int nwin = 0;
         const MsmTuning tu_in = tuning_from(opts);
-        CURVE_SWITCH(c, nwin = msm_windows<C>(msm_pick_c(n, tu_in.window_bits)));
+        CURVE_SWITCH(c, nwin = msm_windows<C>(msm_pick_c(n, tu_in.window_bits, tu_in.precomputed)));
         hipEvent_t ready = nullptr;
         {
             ZK_TRY(bind_device(dc));
@@ -875,10 +881,11 @@ static int batch_on_device(DeviceCtx& dc, zk_curve_t c, const BasesEntry* be, co
     uint32_t per_job = 1;
     {
         int cw = 0, nwin = 0;
-        CURVE_SWITCH(c, cw = msm_pick_c(n, tu.window_bits); nwin = msm_windows<C>(cw));
+        CURVE_SWITCH(c, cw = msm_pick_c(n, tu.window_bits, tu.precomputed); nwin = msm_windows<C>(cw));
         const int nwj = (tu.w0 == 0 && tu.w1 == 0) ? nwin : tu.w1 - tu.w0;
         const uint32_t nbk = 1u << (cw - 1), nranges = nbk > 512 ? nbk / 512 : 1;
-        const uint32_t regions = (uint32_t)(nwj > 0 ? nwj : 1) * nranges;
+        // (the one-bucket-set form: one window of at most 1024 ranges per vector, whatever c)
+        const uint32_t regions = tu.precomputed ? (nranges > 1024 ? nranges : 1024u) : (uint32_t)(nwj > 0 ? nwj : 1) * nranges;
         per_job = 4096 / regions;
         if (per_job > 4) per_job = 4;
         if (per_job < 1) per_job = 1;

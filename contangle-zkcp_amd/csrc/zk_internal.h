@@ -246,7 +246,7 @@ inline int bind_device(DeviceCtx& dc) {
 }
 int stream_scratch(DeviceCtx& dc, hipStream_t st, StreamScratch** out);   // zk_api.cc
 
-int msm_pick_c(uint64_t n, int requested);
+int msm_pick_c(uint64_t n, int requested, bool pre = false);
 template <class C>
 inline int msm_windows(int c) {
     return (C::Fr::BITS + 1 + c - 1) / c;

@@ -200,9 +200,10 @@ int msm_enqueue_group(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typen
             int sl = 0;
             if (items < 8 * lanes && (n >> 1) / sh.nbk >= 8) sl = 1;
             if (items < lanes && (n >> 2) / sh.nbk >= 8) sl = 2;
-            if (pre) {                 // ~nwin * n / nbk entries per bucket: pieces of ~32
+            if (pre) {                 // ~nwin * n / nbk entries per bucket: pieces of ~32; halves while a lane would get < 8 buckets
                 sl = 0;
                 while (sl < 4 && ((n >> (sl + 1)) / sh.nbk) >= 24) sl++;
+                if (sl == 0 && items < 8 * lanes && (n >> 1) / sh.nbk >= 8) sl = 1;
             }
             if (tu.split_log >= 0) sl = tu.split_log > 4 ? 4 : tu.split_log;
             sh.split_log = sl;
@@ -218,7 +219,7 @@ int msm_enqueue_group(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typen
         if (pre && n_real % sh.sblk != 0) return ZK_ERR_UNSUPPORTED;
         const uint32_t nblocks_real = (uint32_t)((n_real + sh.sblk - 1) / sh.sblk);
         const uint32_t nblocks = pre ? nblocks_real * sh.pre_w : nblocks_real;
-        if (nreg > 4096 || sh.nranges > (pre ? 1024u : 64u)) return ZK_ERR_UNSUPPORTED;   // LDS tables of those kernels (c <= 16: <= 1024, 64)
+        if (nreg > 4096 || sh.nranges > (pre ? 1024u : 64u)) return ZK_ERR_UNSUPPORTED;   // LDS tables of those kernels (<= 1024 / 64 ranges per window)
         if ((uint64_t)n * (uint64_t)nw_all >= (1ull << 32)) return ZK_ERR_UNSUPPORTED;   // entry positions are u32 (2^27 points x 16 windows fit)
         // counts | offs | order | wg_total | region_base
         ZK_TRY(ws_get(job.counts, ((size_t)nbuckets * 3 + 2 * (size_t)nreg) * 4));
@@ -231,7 +232,7 @@ int msm_enqueue_group(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typen
         uint32_t* blockcnt = (uint32_t*)job.blockcnt.p;
         ZK_TRY(ws_get(job.stage_idx, (size_t)n * nw_all * 4));
         ZK_TRY(ws_get(job.stage_low, (size_t)n * nw_all * 2));
-        ZK_TRY(ws_get(job.digits, (size_t)n * nw_all * 2));
+        ZK_TRY(ws_get(job.digits, (size_t)n * nw_all * (pre ? 4 : 2)));   // (the one-bucket-set form: 32-bit codes, up to 2^19 buckets)
         uint16_t* digits = (uint16_t*)job.digits.p;
         uint32_t* stage_idx = (uint32_t*)job.stage_idx.p;
         uint16_t* stage_low = (uint16_t*)job.stage_low.p;
@@ -268,9 +269,11 @@ int msm_enqueue_group(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typen
             job.acc_ev.push_back(e);
         }
         // ---- sort: partition the digits by (window, bucket range), then counting-sort every region in LDS
-        const unsigned dblk = sh.sblk >= 4096 ? 1024u : 256u;   // small problems: fewer lanes, cheaper barriers
+        // small problems: fewer lanes, cheaper barriers -- but the stage kernel sets up one lane per range (up to 1024 in the
+        // one-bucket-set form: a wide window over few points)
+        const unsigned dblk = (sh.sblk >= 4096 || sh.nranges > 256) ? 1024u : 256u;
         if (pre)
-            ZK_LAUNCH((msm_digits_pre_kernel<C>), nblocks_real * sh.batch, dblk, (size_t)sh.nranges * 4, st, d_scalars, sh, digits, blockcnt);
+            ZK_LAUNCH((msm_digits_pre_kernel<C>), nblocks_real * sh.batch, dblk, (size_t)sh.nranges * 4, st, d_scalars, sh, (uint32_t*)job.digits.p, blockcnt);
         else
             ZK_LAUNCH((msm_digits_kernel<C>), nblocks * sh.batch, dblk, (size_t)sh.nwb * sh.nranges * 4, st, d_scalars, sh, digits, blockcnt);
         auto lanes_for = [](uint32_t items) {   // workgroup size for a scan over `items` values: a power of two in [64, 1024]
@@ -281,9 +284,14 @@ int msm_enqueue_group(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typen
         ZK_LAUNCH((msm_region_scan_kernel<void>), nreg, lanes_for(nblocks), 0, st, blockcnt, nblocks, wg_total);
         ZK_LAUNCH((msm_region_base_kernel<void>), 1, lanes_for(nreg), 0, st, (const uint32_t*)wg_total, nreg, region_base);
         HIP_TRY(hipEventRecord(ev[1], st));
-        ZK_LAUNCH((msm_stage_kernel<void>), nblocks * (unsigned)nw_all, dblk, (size_t)sh.sblk * 8 + (size_t)(3 * sh.nranges + 1) * 4, st,
-                  (const uint16_t*)digits, sh, (const uint32_t*)blockcnt, (const uint32_t*)wg_total, (const uint32_t*)region_base, nblocks,
-                  stage_idx, stage_low);
+        if (pre)
+            ZK_LAUNCH((msm_stage_kernel<uint32_t>), nblocks * (unsigned)nw_all, dblk, (size_t)sh.sblk * 8 + (size_t)(3 * sh.nranges + 1) * 4, st,
+                      (const uint32_t*)job.digits.p, sh, (const uint32_t*)blockcnt, (const uint32_t*)wg_total, (const uint32_t*)region_base, nblocks,
+                      stage_idx, stage_low);
+        else
+            ZK_LAUNCH((msm_stage_kernel<uint16_t>), nblocks * (unsigned)nw_all, dblk, (size_t)sh.sblk * 8 + (size_t)(3 * sh.nranges + 1) * 4, st,
+                      (const uint16_t*)digits, sh, (const uint32_t*)blockcnt, (const uint32_t*)wg_total, (const uint32_t*)region_base, nblocks,
+                      stage_idx, stage_low);
         HIP_TRY(hipEventRecord(ev[2], st));
         // LDS permutation capacity of a sort workgroup: 1.5x the mean region, at most 24576 entries (61 KB of LDS in all,
         // two workgroups per CU); larger regions are sorted in chunks of half that
@@ -462,7 +470,7 @@ int msm_enqueue_impl(MsmJob& job, const StoredAffine<CK>* bases, const Fe<typena
     job.finish = &msm_finish_impl<C, CK>;
     job.empty = true;
     job.alg_bytes = 0;
-    const int c = msm_pick_c(n, tu.window_bits);
+    const int c = msm_pick_c(n, tu.window_bits, tu.precomputed);
     const int nwin = msm_windows<C>(c);
     int w0 = 0, w1 = nwin;
     if (!(tu.w0 == 0 && tu.w1 == 0)) {
@@ -560,7 +568,7 @@ template <class C>
 int msm_enqueue(MsmJob& job, const BasesCopy& bc, const Fe<typename C::Fr>* d_scalars, uint64_t n, int mont, const MsmTuning& tu) {
     if constexpr (has_f29<C>()) {
         if (tu.precomputed) {
-            if (!bc.pre || tu.base_offset != 0 || bc.pre_c != msm_pick_c(n, tu.window_bits) || bc.pre_w != msm_windows<C>(bc.pre_c))
+            if (!bc.pre || tu.base_offset != 0 || bc.pre_c != msm_pick_c(n, tu.window_bits, true) || bc.pre_w != msm_windows<C>(bc.pre_c))
                 return ZK_ERR_INVALID_ARG;
             return msm_enqueue_impl<C, F29View<C>>(job, (const StoredAffine<F29View<C>>*)bc.pre, d_scalars, n, mont, tu);
         }

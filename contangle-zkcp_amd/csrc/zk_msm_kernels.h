@@ -75,9 +75,14 @@ constexpr uint32_t MSM_SBLK = 4096;   // scalars per workgroup of the digit / st
 
 // u16 digit code: two's complement of the signed digit; positive magnitudes reach 2^15 (0x8000),
 // negative ones only 2^15 - 1, so the code is unambiguous:  neg <=> code > 0x8000.
-__device__ __forceinline__ uint32_t digit_mag(uint32_t code, bool& neg) {
+__device__ __forceinline__ uint32_t digit_mag(uint16_t code, bool& neg) {
     neg = code > 0x8000u;
-    return neg ? 0x10000u - code : code;
+    return neg ? 0x10000u - (uint32_t)code : (uint32_t)code;
+}
+// u32 digit code of the one-bucket-set form (windows of up to 20 bits): magnitude | sign << 31
+__device__ __forceinline__ uint32_t digit_mag(uint32_t code, bool& neg) {
+    neg = (code >> 31) != 0;
+    return code & 0x7fffffffu;
 }
 
 // atomicAdd(&ctr[key], 1) for every lane with `valid`, returning the value before the lane's increment -- but the lanes of
@@ -159,7 +164,7 @@ __global__ void __launch_bounds__(1024) msm_digits_kernel(const Fe<typename C::F
 // digits per range from the block's own writes.
 template <class C>
 __global__ void __launch_bounds__(1024) msm_digits_pre_kernel(const Fe<typename C::Fr>* __restrict__ scalars, MsmShape sh,
-                                                              uint16_t* __restrict__ digits, uint32_t* __restrict__ blockcnt) {
+                                                              uint32_t* __restrict__ digits, uint32_t* __restrict__ blockcnt) {
     using Fr = typename C::Fr;
     ZK_DYN_SHARED(uint32_t, cnt);   // nranges
     const uint32_t R = sh.nranges;
@@ -178,7 +183,7 @@ __global__ void __launch_bounds__(1024) msm_digits_pre_kernel(const Fe<typename 
                 const bool neg = raw > sh.nbk;
                 const uint32_t mag = neg ? (1u << sh.c) - raw : raw;
                 carry = neg ? 1u : 0u;
-                digits[(uint64_t)w * sh.pre_n + i] = (uint16_t)(neg ? 0x10000u - mag : mag);
+                digits[(uint64_t)w * sh.pre_n + i] = mag | (neg ? 0x80000000u : 0u);
             }
         }
     }
@@ -259,9 +264,10 @@ __global__ void __launch_bounds__(1024) msm_region_base_kernel(const uint32_t* _
 // in stage_idx and the bucket number inside the range in stage_low.  The copy is what makes this cheap: a lane-per-digit
 // scatter would issue one 4-byte store request per digit to L2 (33 M requests at 2^20 x 16), the chunk copy issues a
 // few requests per 64-entry chunk.
-// LDS: e_idx[sblk] u32 | starts[R + 1] | gdst[R] | lcur[R] | e_low[sblk] u16 | e_h[sblk] u16      (R = nranges <= 64)
-template <class Tag>
-__global__ void __launch_bounds__(1024) msm_stage_kernel(const uint16_t* __restrict__ digits, MsmShape sh, const uint32_t* __restrict__ blockoff,
+// LDS: e_idx[sblk] u32 | starts[R + 1] | gdst[R] | lcur[R] | e_low[sblk] u16 | e_h[sblk] u16      (R = nranges <= 64; <= 1024 in the
+// one-bucket-set form).  blockDim.x >= R: one lane per range sets up its chunk.
+template <class DT>   // uint16_t codes (a window's digits), uint32_t codes (the one-bucket-set form)
+__global__ void __launch_bounds__(1024) msm_stage_kernel(const DT* __restrict__ digits, MsmShape sh, const uint32_t* __restrict__ blockoff,
                                                          const uint32_t* __restrict__ wg_total, const uint32_t* __restrict__ region_base,
                                                          uint32_t nblocks, uint32_t* __restrict__ stage_idx, uint16_t* __restrict__ stage_low) {
     ZK_DYN_SHARED(uint32_t, lds);
@@ -294,7 +300,7 @@ __global__ void __launch_bounds__(1024) msm_stage_kernel(const uint16_t* __restr
         if (tid < R) starts[tid + 1] += u;
         __syncthreads();
     }
-    const uint16_t* row = digits + (uint64_t)wl * sh.n;
+    const DT* row = digits + (uint64_t)wl * sh.n;
     for (uint32_t k = tid; k < sh.sblk; k += nth) {
         const uint32_t i = blk * sh.sblk + k;
         if (i >= sh.n) break;

@@ -162,6 +162,7 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
     // src0 (optional): the input is read from there by the first pass and left untouched; the result lands in `a` (out of place)
     if (!src0) src0 = a;
     if (logn > (uint32_t)F::TWO_ADICITY || logn > 30) return ZK_ERR_INVALID_ARG;   // before anything is sized from logn
+    if ((uint32_t)((scale_flag >> 4) & 15) > logn || (scale_flag & ~0xf3)) return ZK_ERR_INVALID_ARG;
     if (logn == 0) return ZK_OK;  // size-1 transform is the identity, n^-1 = 1 and g^0 = 1
     // lazy 29-bit limbs inside the tiles (zk_ntt29_kernels.h) unless zk_ntt_opts asks for the saturated words
     const bool lazy = g.ntt_opts.limb_bits != 32;
@@ -170,7 +171,8 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
     if (g_post) ZK_TRY(pow_tables<F>(dc, *g_post, logn, field, st, &tpost, lazy));
     const Fe<F>* tw = nullptr;
     ZK_TRY(tw_table<F>(dc, omega, logn, field, st, &tw, lazy));
-    // scale_flag: bit 0 = multiply by n^-1 ; bit 1 (ZK_NTT_OUT_R29) = leave the results as x R' mod p (R' = 2^261, the lazy-limb
+    // scale_flag: bits 4..7 (ZK_NTT_OUT_SUBCOSETS(log P)) = the last pass stores result k at (k mod P) (n / P) + k / P ;
+    // bit 0 = multiply by n^-1 ; bit 1 (ZK_NTT_OUT_R29) = leave the results as x R' mod p (R' = 2^261, the lazy-limb
     // radix zk_expr_eval_lazy_device reads) instead of x R mod p: the last pass multiplies by 2^5 more
     Fe<F> scale;
     fe_one(scale);
@@ -205,7 +207,8 @@ int ntt_run(DeviceCtx& dc, int field, Fe<F>* a, uint32_t logn, const Fe<F>& omeg
         A.log_r = plan.rd[p];
         A.log_t = plan.log_t[p];
         A.last = (p == plan.nd - 1);
-        A.scale = (A.last && scale_flag) ? 1 : 0;
+        A.scale = (A.last && (scale_flag & 3)) ? 1 : 0;
+        A.out_parts_log = A.last ? ((scale_flag >> 4) & 15) : 0;
         A.nd = plan.nd;
         for (int i = 0; i < plan.nd; i++) A.rd[i] = plan.rd[i];
         A.pre = (p == 0 && g_pre) ? 1 : 0;

@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(1024) ntt_pass29_kernel(const Fe<F>* __restric
             if (A.post) mul_pow29(x, post, go);
             fe29_pack(r, x);
             fe_reduce_once<F>(r.v);
-            out[go] = r;
+            out[ntt_out_index(A, go)] = r;
         }
     }
 }

@@ -156,7 +156,14 @@ struct NttPass {
     int pre;    // first pass multiplies input element i by g_pre^i on load   (ark coset_fft = distribute_powers ; fft)
     int post;   // last pass multiplies output element k by g_post^k on store (ark coset_ifft = ifft ; distribute_powers)
     int in_log; // first pass: only the first 2^in_log input elements are read, the rest count as zero (halo2 coeff_to_extended); 0 = all
+    int out_parts_log;  // last pass: result k is stored at (k mod P) * (n / P) + k / P, P = 2^out_parts_log (ZK_NTT_OUT_SUBCOSETS): the
+                        // transform's P sub-cosets one after another; 0 = natural order
 };
+// where result `go` of the last pass lands
+__device__ __forceinline__ uint64_t ntt_out_index(const NttPass& A, uint64_t go) {
+    if (A.out_parts_log == 0) return go;
+    return ((go & ((1ull << A.out_parts_log) - 1)) << (A.logn - A.out_parts_log)) | (go >> A.out_parts_log);
+}
 
 template <class F>
 __device__ __forceinline__ void tw_get(Fe<F>& w, const Fe<F>* __restrict__ tw, uint64_t e, uint64_t half) {
@@ -294,7 +301,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(const Fe<F>* __restrict_
             const uint64_t go = out_fixed + t + ((uint64_t)k << A.log_m);
             if (A.scale) fe_mul(x, x, scale);
             if (A.post) mul_pow(x, post, go);
-            out[go] = x;
+            out[ntt_out_index(A, go)] = x;
         }
     }
 }

@@ -107,6 +107,43 @@ def gather_parts(local, out, stream=None, group=None):
     return out
 
 
+def gather_stack(local, out, group=None):
+    """device buffers: out[r] = rank r's `local` (out: [world, ...local.shape]); `local` may be out[rank] itself (in place).
+    One all_gather over RCCL; gloo (CPU rehearsal) goes through the host."""
+    world, rank = _world(group)
+    if world == 1:
+        if out[0].data_ptr() != local.data_ptr():
+            out[0].copy_(local)
+        return out
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), group=group)
+    else:
+        t = local.cpu()
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t, group=group)
+        out.copy_(torch.stack(outs).to(out.device))
+    return out
+
+
+def gather_rows(local, max_rows, group=None):
+    """host rows (numpy [rows <= max_rows, w] u64: e.g. a rank's commitments) from every rank, padded to max_rows each:
+    numpy [world * max_rows, w], rank r's rows at r * max_rows.  One all_gather."""
+    world, rank = _world(group)
+    local = np.ascontiguousarray(local, dtype=np.uint64)
+    w = int(local.shape[1])
+    pad = np.zeros((max_rows, w), dtype=np.uint64)
+    pad[:local.shape[0]] = local
+    if world == 1:
+        return pad
+    t = torch.from_numpy(pad.view(np.int64))
+    on_gpu = dist.get_backend(group) == "nccl"
+    if on_gpu:
+        t = t.cuda()
+    out = torch.empty((world * max_rows, w), dtype=torch.int64, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out.cpu().numpy().view(np.uint64)
+
+
 def msm_sharded(bases, scalars, montgomery=False, window_bits=0, group=None, stream=0):
     """All ranks call with the same bases/scalars; returns the full Jacobian sum on every rank."""
     world, rank = _world(group)

@@ -113,19 +113,23 @@ class EvaluationDomain:
             raise AssertionError("assertion failed: a.values.len() == 1 << self.k")
         return ntt(self.field, a, self.omega, stream=stream, device=True)
 
-    def coeff_to_extended(self, a_ext, stream=0, coeffs=None, lazy_out=False):
+    def coeff_to_extended(self, a_ext, stream=0, coeffs=None, lazy_out=False, parts=1):
         """`a_ext`: buffer of extended_len() whose first n entries are the coefficients (the rest is treated as the zeros
         upstream's `resize` appends): distribute_powers_zeta(into_coset) ; best_fft(extended_omega).  coeffs: take the n
-        coefficients from that buffer instead (it is left untouched: the openings evaluate it later)"""
+        coefficients from that buffer instead (it is left untouched: the openings evaluate it later).
+        parts: store the result sub-coset by sub-coset -- a_ext.view(parts, extended_len / parts)[j] is what
+        coeff_to_extended_part(.., j, parts) computes (ZK_NTT_OUT_SUBCOSETS: the same transform, other store addresses)"""
         if int(a_ext.shape[0]) != self.extended_len():
             raise AssertionError("assertion failed: a.len() == extended_len")
+        self._part_check(0, parts)
+        flags = (2 if lazy_out else 0) | ((parts.bit_length() - 1) << 4)
         if coeffs is not None:
             if int(coeffs.shape[0]) != self.n:
                 raise AssertionError("assertion failed: a.len() == 1 << self.k")
             return ntt(self.field, a_ext, self.extended_omega, stream=stream, coset_pre=self.g_coset, in_log=self.k, src=coeffs,
-                       scale_by_n_inv=2 if lazy_out else 0)
+                       scale_by_n_inv=flags)
         return ntt(self.field, a_ext, self.extended_omega, stream=stream, coset_pre=self.g_coset,
-                   in_log=self.k if self.extended_k > self.k else None, device=True, scale_by_n_inv=2 if lazy_out else 0)
+                   in_log=self.k if self.extended_k > self.k else None, device=True, scale_by_n_inv=flags)
 
     def extended_to_coeff(self, a_ext, stream=0):
         """best_fft(extended_omega_inv) ; times extended_ifft_divisor ; distribute_powers_zeta(out of the coset).  Upstream
@@ -171,6 +175,50 @@ class EvaluationDomain:
         g, w = self._part_constants(part, parts)
         return ntt(self.field, out, w, stream=stream, coset_pre=g, in_log=self.k, src=coeffs, scale_by_n_inv=2 if lazy_out else 0)
 
+    def part_to_coeff(self, a_part, part, parts, stream=0):
+        """in place, the inverse of coeff_to_extended_part for a polynomial of degree < extended_len / parts =: m -- and for a
+        longer one (the quotient: degree < extended_len) the sub-coset's FOLDED coefficients
+            A_part[r] = sum_i (g^m)^i h[i m + r],   g = ZETA extended_omega^part   (g^m is the same for every point of the sub-coset)
+        from which quotient_pieces_from_parts recovers h: inverse transform of size m, times 1 / m, times g^-r."""
+        self._part_check(part, parts)
+        if int(a_part.shape[0]) != self.part_len(parts):
+            raise AssertionError("assertion failed: a.len() == extended_len / parts")
+        key = ("inv", part, parts)
+        if key not in self.__dict__.setdefault("_parts", {}):
+            g, w = self._part_constants(part, parts)
+            self._parts[key] = (field_inverse(self.field, g), field_inverse(self.field, w))
+        ginv, winv = self._parts[key]
+        return ntt(self.field, a_part, winv, scale_by_n_inv=True, stream=stream, coset_post=ginv, device=True)
+
+    def part_mix(self, parts):
+        """c[i][j] (Python integers) with  h[i m : (i + 1) m] = sum_j c[i][j] A_j  for the folded coefficients A_j of part_to_coeff:
+        A_j = sum_i (ZETA^m theta^j)^i h^(i), theta = extended_omega^m a primitive parts-th root of unity, so the h^(i) are an inverse
+        DFT of size `parts` over the sub-cosets, scaled: c[i][j] = ZETA^(-m i) theta^(-i j) / parts."""
+        self._part_check(0, parts)
+        p = self._p
+        to_int = lambda a: sum(int(w) << (64 * i) for i, w in enumerate(a.tolist())) * pow(1 << 256, -1, p) % p
+        m = self.part_len(parts)
+        theta = pow(to_int(self.extended_omega), m, p)
+        zm_inv = pow(pow(to_int(self.g_coset), m, p), -1, p)
+        pinv = pow(parts, -1, p)
+        return [[pinv * pow(zm_inv, i, p) * pow(theta, (-i * j) % parts, p) % p for j in range(parts)] for i in range(parts)]
+
+    def piece_scalars(self, parts):
+        """the quotient's pieces of n coefficients (upstream commits each: h(X) = sum_q X^(n q) h_q) as combinations of the n-coefficient
+        slices of the folded sub-coset coefficients: piece q = i r + s (r = m / n slices per part) = sum_j c[i][j] A_j[s n : (s + 1) n].
+        Returns [(q, [(j, s, c_ij), ...])]: by linearity the same combination of the slices' COMMITMENTS is the piece's commitment."""
+        c = self.part_mix(parts)
+        r = self.part_len(parts) // self.n
+        return [(i * r + s, [(j, s, c[i][j]) for j in range(parts)]) for i in range(parts) for s in range(r)]
+
+    def fold_scalars(self, parts, xn_int):
+        """e[j][s] with  sum_q xn^q h_q = sum_{j, s} e[j][s] A_j[s n : (s + 1) n]  (the folded quotient the evaluation phase opens)"""
+        c = self.part_mix(parts)
+        p = self._p
+        r = self.part_len(parts) // self.n
+        xr = pow(xn_int, r, p)
+        return [[pow(xn_int, s, p) * sum(pow(xr, i, p) * c[i][j] for i in range(parts)) % p for s in range(r)] for j in range(parts)]
+
     def divide_by_vanishing_poly_part(self, a_part, part, parts, stream=0):
         """a[i] *= t_evaluations[(i parts + part) mod 2^(extended_k - k)]"""
         self._part_check(part, parts)
@@ -186,6 +234,26 @@ class EvaluationDomain:
         if int(a_ext.shape[0]) != self.extended_len():
             raise AssertionError("assertion failed: a.values.len() == extended_len")
         return vec_op(self.field, "scale_periodic", a_ext, b=self.t_evaluations, stream=stream)
+
+
+def combine_commitments(curve, points_jac, rows, to_device=None, stream=0):
+    """sum_k scalar_k * points[index_k] for every row of `rows` = [[(index, integer scalar), ...], ...]: the commitments of the quotient's
+    pieces from the commitments of the sub-cosets' folded coefficients (EvaluationDomain.piece_scalars) -- commitments are linear, so
+    the pieces never have to exist as vectors before they are committed.  A batched MSM over a throwaway handle of len(points) bases
+    (to_device: host array -> device buffer; without it one host-scalar MSM per row).  Returns [len(rows), 3 * limbs] Jacobian."""
+    from . import point_to_affine
+    aff = np.stack([point_to_affine(curve, pj) for pj in points_jac])
+    cols = np.zeros((len(rows), len(points_jac), 4), dtype=np.uint64)
+    for q, terms in enumerate(rows):
+        for idx, sc in terms:
+            cols[q, idx] = [(int(sc) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)]
+    bases = Bases(curve, aff)
+    try:
+        if to_device is not None:
+            return msm_batch(bases, to_device(cols), stream=stream)
+        return np.stack([msm(bases, cols[q]) for q in range(len(rows))])
+    finally:
+        bases.free()
 
 
 # ------------------------------------------------------------------ prover steps beyond commit / FFT (SURVEY 8f f4)

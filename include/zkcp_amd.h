@@ -203,8 +203,12 @@ int zk_msm_batch_device(zk_curve_t c, uint64_t bases_handle, const void *scalars
  * omega^-1, no implicit scaling).  scale_by_n_inv = 1 additionally multiplies by (2^log_n)^-1
  * (ark-poly ifft_in_place semantics when omega = group_gen_inv).  On the device entry points the argument is a bit set:
  * bit 0 = that scaling; ZK_NTT_OUT_R29 = write the results as x R' mod p, R' = 2^261 (the lazy-limb radix), for a
- * consumer that computes on lazy limbs (zk_expr_eval_lazy_device) -- one constant changes in the last pass, no extra work. */
+ * consumer that computes on lazy limbs (zk_expr_eval_lazy_device) -- one constant changes in the last pass, no extra work;
+ * ZK_NTT_OUT_SUBCOSETS(lp): result k is stored at (k mod P) * (n / P) + k / P, P = 2^lp -- the P sub-cosets of the output domain
+ * one after another (sub-coset j = the points g omega^(i P + j)), which is how a prover that evaluates its quotient sub-coset by
+ * sub-coset wants a column (halo2.py EvaluationDomain.coeff_to_extended(parts=)); only the last pass's store addresses change. */
 #define ZK_NTT_OUT_R29 2
+#define ZK_NTT_OUT_SUBCOSETS(log_parts) (((log_parts) & 15) << 4)
 int zk_ntt(zk_field_t f, void *a_mont_host, uint32_t log_n, const void *omega_mont_host, int scale_by_n_inv);
 int zk_ntt_device(zk_field_t f, void *a_mont_dev, uint32_t log_n, const void *omega_mont_host,
                   int scale_by_n_inv, void *hip_stream);

@@ -566,6 +566,51 @@ def check_multi_device(zk, ndev):
     check_ntt_vs_oracle(zk, "PallasFp", 9)
 
 
+def check_quotient_by_parts(zk, name, cname, k, parts, seed=77, direct_pieces=None):
+    """the quotient through its sub-cosets: part_to_coeff of every sub-coset's values + the mixing scalars reproduce upstream's
+    extended_to_coeff (every coefficient, through Python integers), the folded h(X) = sum_q x^(n q) h_q, and -- commitments being
+    linear -- the pieces' commitments as combinations of the sub-cosets' (against the MSM of the piece itself and the oracle)"""
+    p = pyref.FIELDS[name][0]
+    dom = zk.halo2.EvaluationDomain(name, 9, k)
+    n, ne = 1 << k, dom.extended_len()
+    m, r = ne // parts, (ne // parts) // n
+    unmont = lambda a: orc.limbs_to_int(orc.from_mont(name, a.reshape(1, 4))[0])
+    h_ext = rand_field(name, ne, seed)
+    coeffs = to_host(zk, dom.extended_to_coeff(to_device(zk, h_ext.copy())))                     # upstream's path
+    A = []
+    for j in range(parts):
+        A.append(to_host(zk, dom.part_to_coeff(to_device(zk, np.ascontiguousarray(h_ext[j::parts])), j, parts)))
+    c = dom.part_mix(parts)
+    Ai = [[unmont(a[t]) for t in range(m)] for a in A]
+    ci = [unmont(coeffs[t]) for t in range(ne)]
+    for i in range(parts):
+        for t in range(m):
+            assert sum(c[i][j] * Ai[j][t] for j in range(parts)) % p == ci[i * m + t], (name, k, parts, i, t)
+    # the folded quotient
+    xn = 0x1234567 * 0x89abcdef % p
+    e = dom.fold_scalars(parts, xn)
+    for t in (0, 1, n // 2, n - 1):
+        exp = sum(pow(xn, q, p) * ci[q * n + t] for q in range(ne // n)) % p
+        got = sum(e[j][s_] * Ai[j][s_ * n + t] for j in range(parts) for s_ in range(r)) % p
+        assert got == exp, (name, k, parts, "fold", t)
+    # the pieces' commitments
+    pts = bases_for(cname, n)
+    bases = zk.Bases(cname, pts)
+    C, index = [], {}
+    for j in range(parts):
+        for s_ in range(r):
+            index[(j, s_)] = len(C)
+            C.append(zk.msm(bases, to_device(zk, np.ascontiguousarray(A[j][s_ * n:(s_ + 1) * n])), montgomery=True))
+    rows = dom.piece_scalars(parts)
+    got = zk.halo2.combine_commitments(cname, C, [[(index[(j, s_)], sc) for j, s_, sc in terms] for _, terms in rows])
+    for (q, _), gq in list(zip(rows, got))[:direct_pieces]:
+        direct = zk.msm(bases, to_device(zk, np.ascontiguousarray(coeffs[q * n:(q + 1) * n])), montgomery=True)
+        assert (affine_of(zk, cname, gq) == affine_of(zk, cname, direct)).all(), (name, k, parts, "piece", q)
+    q0 = rows[0][0]
+    assert (affine_of(zk, cname, got[0]) == orc.msm_ark(cname, pts, orc.from_mont(name, coeffs[q0 * n:(q0 + 1) * n]), threads=4)).all()
+    bases.free()
+
+
 # ------------------------------------------------------------------ halo2 EvaluationDomain (poly/domain.rs)
 PASTA_ZETA = {   # pasta_curves 0.4 FieldExt::ZETA (SURVEY.md Appendix A: 5^((p-1)/3))
     "PallasFp": 0x2d33357cb532458ed3552a23a8554e5005270d29d19fc7d27b7fd22f0201b547,
@@ -643,6 +688,16 @@ def check_halo2_domain(zk, name, k, j=9):
             dom.divide_by_vanishing_poly_part(d_pt, part, parts)
             assert (to_host(zk, d_pt) == exp_div_all[part::parts]).all(), (name, k, part, parts, "divide_by_vanishing_poly_part")
         assert dom.rot_scale_part(parts) * parts == 1 << (ek - k)
+        # ... and all of them from ONE transform of the whole coset that stores sub-coset by sub-coset (ZK_NTT_OUT_SUBCOSETS), out of
+        # place from the coefficients and in place from the zero-padded buffer
+        d_co, d_all = to_device(zk, coeffs), to_device(zk, np.full((ne, 4), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64))
+        dom.coeff_to_extended(d_all, coeffs=d_co, parts=parts)
+        got_all = to_host(zk, d_all).reshape(parts, ne // parts, 4)
+        for part in range(parts):
+            assert (got_all[part] == exp_ext[part::parts]).all(), (name, k, part, parts, "coeff_to_extended(parts=)")
+        got_all = to_host(zk, dom.coeff_to_extended(to_device(zk, dirty), parts=parts)).reshape(parts, ne // parts, 4)
+        for part in range(parts):
+            assert (got_all[part] == exp_ext[part::parts]).all(), (name, k, part, parts, "coeff_to_extended(parts=) in place")
         parts *= 2
     # divide_by_vanishing_poly
     tt = [mont(v) for v in t_exp]

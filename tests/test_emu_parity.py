@@ -112,6 +112,7 @@ def test_msm_precomputed_table(zk):
     ps.check_msm_precomputed(zk, "Vesta", 512, 8, count=3)
     ps.check_msm_precomputed(zk, "Bls381G1", 256, 6, realistic=True)
     ps.check_msm_precomputed(zk, "Bn254G2", 256, 5)
+    ps.check_msm_precomputed(zk, "Pallas", 256, 17, count=2)    # wider than a u16 digit code: the 32-bit codes of this form
 
 
 def test_msm_window_groups(zk):
@@ -172,6 +173,10 @@ def test_halo2_domain(zk):
     ps.check_halo2_domain(zk, "PallasFp", 5)          # degree-9 gates: extended_k = k + 3
     ps.check_halo2_domain(zk, "PallasFq", 4, j=5)     # extended_k = k + 2
     ps.check_halo2_domain(zk, "PallasFp", 3, j=2)     # nothing to extend
+
+
+def test_quotient_by_parts(zk):
+    ps.check_quotient_by_parts(zk, "PallasFp", "Vesta", 3, 4, direct_pieces=2)      # two pieces per sub-coset (the GPU tier: 8, 4, 2, 1 parts)
 
 
 def test_groth16_prove_end_to_end(zk):

@@ -152,7 +152,10 @@ def test_msm_slice_lengths(zk, cname):
 
 
 @pytest.mark.parametrize("cname,n,wb,count", [("Vesta", 1 << 16, 16, 3), ("Pallas", 1 << 18, 0, 0), ("Bls381G1", 1 << 14, 12, 2),
-                                              ("Bn254G2", 1 << 13, 10, 0), ("Vesta", 1 << 20, 0, 5)])
+                                              ("Bn254G2", 1 << 13, 10, 0), ("Vesta", 1 << 20, 0, 5),
+                                              # windows wider than 16 bits (32-bit digit codes; 0 = the form's own choice: 18 / 20 bits above)
+                                              ("Vesta", 1 << 16, 17, 3), ("Bls381G1", 1 << 16, 18, 2), ("Bn254G1", 1 << 17, 20, 0),
+                                              ("Bls381G2", 1 << 14, 19, 0)])
 def test_msm_precomputed_table(zk, cname, n, wb, count):
     ps.check_msm_precomputed(zk, cname, n, wb, realistic=(cname == "Bls381G1"), count=count)
 
@@ -363,6 +366,11 @@ def test_invalid_arguments_are_refused(zk):
 @pytest.mark.parametrize("name,k,j", [("PallasFp", 10, 9), ("PallasFq", 11, 9), ("PallasFp", 9, 5), ("Bls381Fr", 8, 3)])
 def test_halo2_domain(zk, name, k, j):
     ps.check_halo2_domain(zk, name, k, j)
+
+
+@pytest.mark.parametrize("name,cname,k,parts", [("PallasFp", "Vesta", 7, 8), ("PallasFp", "Vesta", 6, 4), ("PallasFq", "Pallas", 6, 2), ("PallasFp", "Vesta", 5, 1)])
+def test_quotient_by_parts(zk, name, cname, k, parts):
+    ps.check_quotient_by_parts(zk, name, cname, k, parts)
 
 
 # ------------------------------------------------------------------ BASELINE configs[2] / [3] / [4] at their full sizes
