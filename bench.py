@@ -243,6 +243,16 @@ def rooflines(e, workload_key):
 
 def emit(e, line, roofs):
     """the dominant kernel (most kernel time in the timed region) is `roofline`; the other hot kernel rides along"""
+    for r in roofs.values():
+        # both kernels are bound by vector-ALU issue, not by HBM: the second figure every roofline entry carries
+        if r.get("valu_wave_insts_per_launch"):
+            peak = 256 * 4 * 2.4e9 / 4
+            v = r["valu_wave_insts_per_launch"] / (r["avg_launch_us"] * 1e-6)
+            r["valu_issue"] = {"achieved_winst_s": v, "peak_winst_s": peak, "frac": v / peak,
+                               "note": "SQ_INSTS_VALU per launch (profiles/traffic.json: same kernel sources) / mean launch time; peak = 1024 SIMDs x 2.4 GHz / 4 "
+                                       "cycles per wave instruction.  Launches of the work-list share the CUs with kernels of other streams: run alone the "
+                                       "NTT pass measures 0.40 ms for the 2^23 middle pass = 2.1e8 wave instructions (profiles/r03_h_*), the accumulate "
+                                       "kernel 0.93 of this peak (column workload)"}
     if roofs:
         order = sorted(roofs.values(), key=lambda r: -r["kernel_ms_total"])
         line["roofline"] = order[0]
@@ -374,8 +384,8 @@ def bench_halo2(e):
     # ---- chains: every committed Lagrange column -> coefficients (kept) -> this rank's sub-coset of the extended domain
     chain_names = [("inst", c) for c in range(N_INST)] + [("adv", c) for c in range(NCOL)] + [("lk", "A'"), ("lk", "S'"), ("lk", "Z")] + [("zp", c) for c in range(3)]
     d_cos = {nm: newbuf(PL, m) for nm in chain_names}
-    d_zl = newbuf(n)
-    d_zp = newbuf(3, n)
+    d_z = newbuf(4, n)                           # the grand products Z_P (3 chunks) and Z_L: one buffer, one batched commitment
+    d_zp, d_zl = d_z[:3], d_z[3]
     d_hp = newbuf(PL, m)                       # the quotient's numerator on this rank's sub-cosets, then their folded coefficients
     hp_flat = d_hp.view(PL * r_sl, n, 4)       # ... as n-coefficient slices: what gets committed
     d_hsum = newbuf(e.world, n) if e.world > 1 else None
@@ -461,23 +471,28 @@ def bench_halo2(e):
             lo, hi = c * PERM_CHUNK, min(N_PERM_COLS, (c + 1) * PERM_CHUNK)
             z_first = H.permutation_product(sfield, pcols[lo:hi], d_sigma[lo:hi], beta, gamma, delta, k, d_zp[c], first_column_index=lo,
                                             z_first=z_first, stream=e.st)
+        # ---- 4 lookup product.  Upstream writes the Z_P commitments, then the Z_L commitment, and squeezes no challenge in between
+        # (both products only need beta, gamma): the four go into ONE batched commitment, behind both products
+        H.lookup_product(sfield, d_lookup[0], d_lookup[1], d_lookup[2], d_lookup[3], beta, gamma, d_zl, stream=e.st)
         ev_zp.record(main)
         side.wait_event(ev_zp)
         with torch.cuda.stream(side):
             for c in range(3):
                 chain(("zp", c), d_zp[c], side.cuda_stream)
-        commit_batch(g_lagrange, d_zp)
-        t3 = time.perf_counter()
-        # ---- 4 lookup product
-        H.lookup_product(sfield, d_lookup[0], d_lookup[1], d_lookup[2], d_lookup[3], beta, gamma, d_zl, stream=e.st)
-        ev_zl.record(main)
-        side.wait_event(ev_zl)
-        with torch.cuda.stream(side):
             chain(("lk", "Z"), d_zl, side.cuda_stream)
-        commit(g_lagrange, d_zl)
-        t4 = time.perf_counter()
+        # the vanishing argument's random polynomial (5) depends on nothing but the RNG: its commitment (coefficient basis, another
+        # key) runs on a library stream of its own beside the batch
+        t_rand = None
+        if e.world == 1 and not a.serial:
+            t_rand = zk.msm_submit(g_coeff, d_coef[row[("random", 0)]], montgomery=True, window_bits=a.window_bits, stream=e.st, own_stream=True)
+        commit_batch(g_lagrange, d_z)
+        t3 = time.perf_counter()
+        t4 = t3
         # ---- 5 vanishing argument's random polynomial, 6 quotient
-        commit(g_coeff, d_coef[row[("random", 0)]])
+        if t_rand is not None:
+            result["random_commitment"] = t_rand.collect()
+        else:
+            result["random_commitment"] = commit(g_coeff, d_coef[row[("random", 0)]])
         main.wait_stream(side)                                      # every coset (and coefficient form) is complete from here on
         xn_int = to_int(xn)
         cols_of = lambda jj: ([d_cos[("adv", c)][jj] for c in range(NCOL)] + [d[jj] for d in d_fixed_cos]
@@ -552,7 +567,11 @@ def bench_halo2(e):
                            H.eval_polynomials(sfield, d_coef[sets[2][0]:sets[2][0] + sets[2][1]], x_prev, stream=e.st),
                            H.eval_polynomials(sfield, d_coef[sets[3][0]:], x_last, stream=e.st)]
         t6 = time.perf_counter()
-        # ---- 8 multiopen
+        # ---- 8 multiopen.  (The opening's blinding polynomial s depends on nothing but the RNG: its commitment is submitted here, on a
+        # library stream of its own, and collected where upstream writes it -- at the start of the inner-product argument.)
+        t_s = None
+        if e.world == 1 and not a.serial:
+            t_s = zk.msm_submit(g_coeff, d_spoly, montgomery=True, window_bits=a.window_bits, stream=e.st, own_stream=True)
         for s_, (first, cnt, pts) in enumerate(sets):          # each set's polynomials folded with x_1: one pass per set
             H.vec_fold_many(sfield, d_q[s_], d_coef[first:first + cnt], x1, stream=e.st)
         for s_, (first, cnt, pts) in enumerate(sets):          # q' = q' x_2 + (set polynomial / prod (X - point))
@@ -570,7 +589,7 @@ def bench_halo2(e):
         if timed_:
             take_class("commit")
         # ---- 9 opening: the inner-product argument on p at x_3
-        commit(g_coeff, d_spoly)
+        result["s_commitment"] = t_s.collect() if t_s is not None else commit(g_coeff, d_spoly)
         H.vec_muladd(sfield, d_spoly, d_qprime, xi, stream=e.st, out=d_ipa[0])            # p' = s xi + p
         result["v"] = H.eval_polynomial(sfield, d_ipa[0], x3, stream=e.st)               # (p'[0] -= v: one element, host side upstream)
         H.vec_powers(sfield, d_ipa[1], x3, stream=e.st)                                  # b

@@ -111,6 +111,16 @@ def gather_stack(local, out, group=None):
     """device buffers: out[r] = rank r's `local` (out: [world, ...local.shape]); `local` may be out[rank] itself (in place).
     One all_gather over RCCL; gloo (CPU rehearsal) goes through the host."""
     world, rank = _world(group)
+    if isinstance(local, np.ndarray):                                  # CPU tests: "device" memory is host memory
+        if world == 1:
+            out[0] = local
+            return out
+        t = torch.from_numpy(np.ascontiguousarray(local).view(np.int64))
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t, group=group)
+        for r_, o in enumerate(outs):
+            out[r_] = o.numpy().view(np.uint64).reshape(local.shape)
+        return out
     if world == 1:
         if out[0].data_ptr() != local.data_ptr():
             out[0].copy_(local)

@@ -153,6 +153,80 @@ def _quotient_worker(rank, world, port, emu_path, q):
     q.put((rank, ok))
 
 
+def _quotient_parts_worker(rank, world, port, emu_path, q):
+    """the quotient AND its commitments sharded by sub-coset (bench.py at N > 1): rank r owns sub-cosets j = r mod world of 8, brings each
+    to its folded coefficients (part_to_coeff), commits them over the whole SRS, and the ranks exchange the commitments (gather_rows)
+    and one folded vector each (gather_stack); the pieces' commitments and the folded h(X) equal upstream's order on every rank"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contangle_zkcp_amd as zk
+    from contangle_zkcp_amd import dist as zkdist
+    import parity_suite as ps
+    from oracle import zk_oracle as orc
+    zk.load(path=emu_path)
+    zk.init(0)
+    name, cname, k, QP = "PallasFp", "Vesta", 2, 8
+    dom = zk.halo2.EvaluationDomain(name, 9, k)
+    n, ne, p = dom.n, dom.extended_len(), dom._p
+    m, r_sl = ne // QP, (ne // QP) // n
+    h_ext = ps.rand_field(name, ne, 4242)                     # the divided numerator on the whole coset (the same on every rank)
+    pts = ps.bases_for(cname, n)
+    bases = zk.Bases(cname, pts)
+    unmont = lambda a: orc.limbs_to_int(orc.from_mont(name, a.reshape(1, 4))[0])
+    mont = lambda v: zk.halo2._mont_limbs(v % p, p)
+    my = [j for j in range(QP) if j % world == rank]
+    A = [dom.part_to_coeff(np.ascontiguousarray(h_ext[j::QP]), j, QP) for j in my]
+    C_loc = np.stack([zk.msm(bases, A[jj][s_ * n:(s_ + 1) * n].copy(), montgomery=True) for jj in range(len(my)) for s_ in range(r_sl)])
+    max_rows = -(-QP // world) * r_sl
+    C_all = zkdist.gather_rows(C_loc, max_rows)
+    order = {}
+    for rk in range(world):
+        for jj, j in enumerate(jx for jx in range(QP) if jx % world == rk):
+            for s_ in range(r_sl):
+                order[(j, s_)] = rk * max_rows + jj * r_sl + s_
+    used = sorted(order.values())
+    C_used, order = C_all[used], {kk: used.index(v) for kk, v in order.items()}
+    rows = dom.piece_scalars(QP)
+    got = zk.halo2.combine_commitments(cname, C_used, [[(order[(j, s_)], sc) for j, s_, sc in terms] for _, terms in rows])
+    # the folded quotient: this rank's share, then the ranks' shares added
+    xn = 0x1234567 * 0x89abcdef % p
+    e_js = dom.fold_scalars(QP, xn)
+    share = np.zeros((n, 4), dtype=np.uint64)
+    first = True
+    for jj, j in enumerate(my):
+        for s_ in range(r_sl):
+            sl = np.ascontiguousarray(A[jj][s_ * n:(s_ + 1) * n])
+            if first:
+                share = zk.vec_op(name, "scale", sl.copy(), scalar=mont(e_js[j][s_]))
+                first = False
+            else:
+                zk.halo2.vec_muladd(name, sl, share, mont(e_js[j][s_]), out=share)
+    shares = np.zeros((world, n, 4), dtype=np.uint64)
+    zkdist.gather_stack(share, shares)
+    folded = shares[0].copy()
+    for rk in range(1, world):
+        zk.vec_op(name, "add", folded, shares[rk])
+    # upstream's order on every rank
+    coeffs = dom.extended_to_coeff(h_ext.copy())
+    ok = True
+    for (qi, _), gq in zip(rows, got):
+        direct = zk.msm(bases, np.ascontiguousarray(coeffs[qi * n:(qi + 1) * n]), montgomery=True)
+        ok &= bool((zk.point_to_affine(cname, gq) == zk.point_to_affine(cname, direct)).all())
+    pieces = np.ascontiguousarray(coeffs.reshape(ne // n, n, 4))
+    exp = np.zeros((n, 4), dtype=np.uint64)
+    zk.halo2.vec_fold_many(name, exp, pieces, mont(xn), reverse=True)
+    ok &= bool((folded == exp).all())
+    bases.free()
+    zk.shutdown()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
 def _run(worker, world):
     import importlib.util
     spec = importlib.util.spec_from_file_location("zk_build", os.path.join(ROOT, "contangle-zkcp_amd", "build.py"))
@@ -175,6 +249,11 @@ def _run(worker, world):
 @pytest.mark.parametrize("world", [2, 4])
 def test_quotient_coset_sharded_gloo(world):
     _run(_quotient_worker, world)
+
+
+@pytest.mark.parametrize("world", [2, 3])      # 3: an uneven deal of the 8 sub-cosets
+def test_quotient_by_parts_gloo(world):
+    _run(_quotient_parts_worker, world)
 
 
 @pytest.mark.parametrize("world", [2, 3])
