@@ -368,7 +368,8 @@ def test_halo2_domain(zk, name, k, j):
     ps.check_halo2_domain(zk, name, k, j)
 
 
-@pytest.mark.parametrize("name,cname,k,parts", [("PallasFp", "Vesta", 7, 8), ("PallasFp", "Vesta", 6, 4), ("PallasFq", "Pallas", 6, 2), ("PallasFp", "Vesta", 5, 1)])
+@pytest.mark.parametrize("name,cname,k,parts", [("PallasFp", "Vesta", 7, 8), ("PallasFp", "Vesta", 6, 4), ("PallasFq", "Pallas", 6, 2), ("PallasFp", "Vesta", 5, 1),
+                                                ("PallasFp", "Vesta", 11, 8)])
 def test_quotient_by_parts(zk, name, cname, k, parts):
     ps.check_quotient_by_parts(zk, name, cname, k, parts)
 
