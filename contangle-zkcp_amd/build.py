@@ -88,7 +88,7 @@ def build_hip(force=False, verbose=False, jobs=None):
     base = [hipcc_path(), "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
             "-fno-gpu-rdc", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     objs = _compile_all(base, objdir, [], verbose, jobs)
-    _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB + ".tmp"] + objs, verbose)
+    _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB + ".tmp"] + objs + ["-lhiprtc", "-ldl"], verbose)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

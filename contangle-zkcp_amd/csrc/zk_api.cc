@@ -1552,6 +1552,13 @@ API int zk_expr_eval_lazy_device(zk_field_t f, const zk_expr_op* prog, uint32_t 
     return ZK_ERR_INVALID_ARG;
 }
 
+API int zk_expr_configure(int jit_mode) {
+    if (jit_mode < 0 || jit_mode > 2) return ZK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.expr_jit = jit_mode;
+    return ZK_OK;
+}
+
 API int zk_field_modulus(zk_field_t f, void* out) {
     if (!out) return ZK_ERR_INVALID_ARG;
     FIELD_SWITCH(f, memcpy(out, F::P, sizeof(uint32_t) * F::N));

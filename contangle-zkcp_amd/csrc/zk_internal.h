@@ -188,6 +188,7 @@ struct Ctx {
     zk_ntt_opts ntt_opts;     // process-wide NTT plan knobs (zk_ntt_configure)
     zk_msm_totals totals;     // sums over the collected jobs (zk_msm_profile_totals)
     bool ntt_profile = false;
+    int expr_jit = 0;         // zk_expr_configure: 0 = specialised quotient kernel for large evaluations, 1 = always, 2 = never (interpreter)
 };
 extern Ctx g;
 

@@ -386,7 +386,7 @@ int expr_eval_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const v
 //   a slot pushed to LDS is always normalised (<= 2^29 + 6) with value <= 32 p, so only the top of the stack ever needs fixing
 template <class F>
 int expr_compile29(const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, const void* const* cols, uint32_t n_consts, std::vector<uint64_t>& words,
-                   uint32_t& depth_out) {
+                   uint32_t& depth_out, uint32_t nslots = EXPR29_SLOTS) {
     using K = F29<F>;
     const double W29 = (double)(1u << K::W), STRICT = W29 - 1, NP = W29 + 6, U32 = 4294967296.0, U64 = 18446744073709551616.0;
     const double ptop1 = (double)K::P[K::L - 1] + 1;
@@ -417,8 +417,9 @@ int expr_compile29(const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, cons
         uint32_t col = 0;
         int rot = 0;
         uint32_t next = 0;
-    } slots[EXPR29_SLOTS];
-    const uint32_t nslots = EXPR29_SLOTS, hoist = 12;
+    } slots[EXPR_JIT_SLOTS_MAX];
+    if (nslots < 1 || nslots > EXPR_JIT_SLOTS_MAX) return ZK_ERR_INVALID_ARG;
+    const uint32_t hoist = 12;
     auto norm_top = [&]() {
         emit(EXPR29_NORM, 0, 0);
         st.back().lb = NP;
@@ -551,6 +552,152 @@ int expr_compile29(const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, cons
     return ZK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The quotient numerator SPECIALISED PER PROGRAM.  expr_eval29_kernel interprets the bound-annotated program: 38 500 VALU
+// instructions per row for the bench's 268-op / 81-product program, of which the products are 17 000 -- the rest is the stack
+// machine (every push spills the top of the stack to LDS and unpacks a cell: ~110 instructions, 122 pushes per row).  A gate
+// expression is fixed per proving key, so the same annotated program -- same operations, same carry steps, same bias tables: the
+// bound walk of expr_compile29 stays the one authority -- is written out as straight-line HIP with the stack resolved at
+// generation time (every intermediate a named value, no LDS), compiled once with hiprtc and cached: ~20 000 instructions per
+// row.  Not available in the CPU test emulator (the interpreter runs there); any failure to build falls back to the interpreter.
+#if !defined(ZK_EMU) && defined(ZK_FIELD)
+}  // namespace zk
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+namespace zk {
+#define ZK_STR2_(x) #x
+#define ZK_STR_(x) ZK_STR2_(x)
+struct ExprJitKernel {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    bool failed = false;
+};
+
+template <class F>
+std::string expr_jit_source(const std::vector<uint64_t>& words, uint32_t nslots, int waves) {
+    static const char* const bias_names[5] = {"BIAS4K1", "BIAS4K2", "BIAS8K2", "BIAS8K3", "BIAS16K2"};   // ids of fe29_sub_by_id
+    std::string s;
+    s.reserve(words.size() * 96 + 1024);
+    char buf[256];
+    s += "#include \"zk_field29.h\"\nusing namespace zk;\nusing F = " ZK_STR_(ZK_FIELD) ";\nusing K = F29<F>;\n";
+    snprintf(buf, sizeof buf, "extern \"C\" __global__ void __launch_bounds__(64, %d) zk_expr_jit(const Fe<F>* const* __restrict__ cols, "
+                              "const Fe<F>* __restrict__ consts, unsigned int log_n, unsigned int rot_scale, Fe<F>* __restrict__ out) {\n", waves);
+    s += buf;
+    s += "  const unsigned long long n = 1ull << log_n, mask = n - 1;\n"
+         "  for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 64) {\n"
+         "    Fe<F> ";
+    for (uint32_t q = 0; q < nslots; q++) {
+        snprintf(buf, sizeof buf, "%ss%u", q ? ", " : "", q);
+        s += buf;
+    }
+    s += ";\n";
+    std::vector<int> st;
+    int nt = 0;
+    for (uint64_t w : words) {
+        const uint32_t op = (uint32_t)(w & 0xff), arg = (uint32_t)(w >> 32);
+        const int rot = (int)(int16_t)(uint16_t)(w >> 16);
+        if (op == EXPR29_LOAD) {
+            snprintf(buf, sizeof buf, "    s%u = cols[%u][(i + (unsigned long long)((long long)%d * (long long)rot_scale)) & mask];\n", (arg >> 16) % nslots, arg & 0xffffu, rot);
+            s += buf;
+        } else if (op == 0 || op == 1) {
+            if (op == 0)
+                snprintf(buf, sizeof buf, "    Fe29<F> t%d; fe29_unpack(t%d, s%u);\n", nt, nt, arg % nslots);
+            else
+                snprintf(buf, sizeof buf, "    Fe29<F> t%d; fe29_unpack(t%d, consts[%u]);\n", nt, nt, arg);
+            s += buf;
+            st.push_back(nt++);
+        } else if (op == 5) {
+            if (st.empty()) return std::string();
+            snprintf(buf, sizeof buf, "    Fe29<F> t%d, z%d; fe29_zero(z%d); fe29_sub(t%d, z%d, t%d, K::%s);\n", nt, nt, nt, nt, nt, st.back(), bias_names[arg < 5 ? arg : 4]);
+            s += buf;
+            st.back() = nt++;
+        } else if (op == 6) {
+            if (st.empty()) return std::string();
+            snprintf(buf, sizeof buf, "    Fe29<F> t%d, c%d; fe29_unpack(c%d, consts[%u]); fe29_mul(t%d, t%d, c%d);\n", nt, nt, nt, arg, nt, st.back(), nt);
+            s += buf;
+            st.back() = nt++;
+        } else if (op == EXPR29_NORM) {
+            if (st.empty()) return std::string();
+            snprintf(buf, sizeof buf, "    fe29_norm(t%d, t%d);\n", st.back(), st.back());
+            s += buf;
+        } else if (op == EXPR29_REFRESH) {
+            if (st.empty()) return std::string();
+            snprintf(buf, sizeof buf, "    { Fe29<F> o; fe29_one(o); fe29_mul(t%d, t%d, o); }\n", st.back(), st.back());
+            s += buf;
+        } else if (op >= 2 && op <= 4) {
+            if (st.size() < 2) return std::string();
+            const int b = st.back(), a = st[st.size() - 2];
+            if (op == 2)
+                snprintf(buf, sizeof buf, "    Fe29<F> t%d; fe29_add(t%d, t%d, t%d);\n", nt, nt, a, b);
+            else if (op == 3)
+                snprintf(buf, sizeof buf, "    Fe29<F> t%d; fe29_sub(t%d, t%d, t%d, K::%s);\n", nt, nt, a, b, bias_names[arg < 5 ? arg : 4]);
+            else
+                snprintf(buf, sizeof buf, "    Fe29<F> t%d; fe29_mul(t%d, t%d, t%d);\n", nt, nt, a, b);
+            s += buf;
+            st.pop_back();
+            st.back() = nt++;
+        } else {
+            return std::string();
+        }
+    }
+    if (st.size() != 1) return std::string();
+    snprintf(buf, sizeof buf, "    Fe<F> r; fe29_to_std(r, t%d); out[i] = r;\n  }\n}\n", st.back());
+    s += buf;
+    return s;
+}
+
+// where the headers the generated source includes live: next to the library (<dir of libzkcp_amd.so>/csrc), or ZKCP_AMD_CSRC
+inline std::string expr_jit_include_dir() {
+    if (const char* e = getenv("ZKCP_AMD_CSRC")) return e;
+    Dl_info info;
+    if (dladdr((const void*)&expr_jit_include_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t k = p.find_last_of('/');
+        return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/csrc";
+    }
+    return "csrc";
+}
+
+// the compiled kernel of (source, device), built on first use; nullptr when it cannot be built (the caller interprets instead)
+template <class F>
+ExprJitKernel* expr_jit_get(DeviceCtx& dc, const std::string& src) {
+    static std::map<std::pair<int, std::string>, ExprJitKernel> cache;      // (called with dc.mu held; one cache per field unit)
+    auto key = std::make_pair(dc.device, src);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second.failed ? nullptr : &it->second;
+    ExprJitKernel& k = cache[key];
+    k.failed = true;
+    const bool verbose = getenv("ZK_EXPR_STATS") != nullptr;
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "zk_expr_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return nullptr;
+    const std::string inc = "-I" + expr_jit_include_dir();
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffreestanding", inc.c_str()};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        if (verbose) {
+            size_t ls = 0;
+            hiprtcGetProgramLogSize(prog, &ls);
+            std::vector<char> log(ls + 1, 0);
+            if (ls) hiprtcGetProgramLog(prog, log.data());
+            fprintf(stderr, "expr jit: compilation failed (%s): %.1500s\n", hiprtcGetErrorString(rc), log.data());
+        }
+        hiprtcDestroyProgram(&prog);
+        return nullptr;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    const bool got = cs && hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
+    hiprtcDestroyProgram(&prog);
+    if (!got || hipModuleLoadData(&k.mod, code.data()) != hipSuccess) return nullptr;
+    if (hipModuleGetFunction(&k.fn, k.mod, "zk_expr_jit") != hipSuccess) return nullptr;
+    if (verbose) fprintf(stderr, "expr jit: %zu bytes of source -> %zu bytes of code object\n", src.size(), cs);
+    k.failed = false;
+    return &k;
+}
+#endif
+
 // columns: x R' mod p (R' = 2^261), canonical words; constants: standard Montgomery on the host (converted here); out: standard
 template <class F>
 int expr_eval_lazy_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const Fe<F>* consts,
@@ -558,7 +705,20 @@ int expr_eval_lazy_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, co
     if (n_ops == 0 || n_ops > EXPR_MAX_OPS || n_cols > EXPR_MAX_COLS || n_consts > EXPR_MAX_CONSTS || log_n > 30) return ZK_ERR_INVALID_ARG;
     std::vector<uint64_t> words;
     uint32_t depth = 0;
-    ZK_TRY(expr_compile29<F>(prog, n_ops, n_cols, cols, n_consts, words, depth));
+    // specialised kernel (g.expr_jit: 0 = for evaluations of 2^16 rows and more, 1 = always, 2 = never): the same annotated program with
+    // more column slots (they are named values there, not a select network)
+    bool want_jit = false;
+#if !defined(ZK_EMU) && defined(ZK_FIELD)
+    want_jit = g.expr_jit == 1 || (g.expr_jit == 0 && log_n >= 16);
+#endif
+    const uint32_t nslots = want_jit ? EXPR_JIT_SLOTS : EXPR29_SLOTS;
+    ZK_TRY(expr_compile29<F>(prog, n_ops, n_cols, cols, n_consts, words, depth, nslots));
+    if (getenv("ZK_EXPR_STATS")) {     // (diagnostic) the executed program by opcode: what the bound walk added to the caller's ops
+        uint32_t cnt[16] = {0};
+        for (uint64_t w : words) cnt[w & 15]++;
+        fprintf(stderr, "expr29: %u caller ops -> %zu executed: push col %u const %u add %u sub %u mul %u neg %u scale %u norm %u refresh %u load %u, depth %u\n",
+                n_ops, words.size(), cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[EXPR29_NORM], cnt[EXPR29_REFRESH], cnt[EXPR29_LOAD], depth);
+    }
     std::vector<Fe<F>> c29(n_consts ? n_consts : 1);
     constexpr int SH = F29<F>::W * F29<F>::L - 32 * F::N;      // x R -> x R': times 2^5
     for (uint32_t i = 0; i < n_consts; i++) {
@@ -575,6 +735,30 @@ int expr_eval_lazy_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, co
     if (n_consts) HIP_TRY(hipMemcpyAsync(base + pb + cb, c29.data(), sizeof(Fe<F>) * n_consts, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));   // the sources are host temporaries
     const uint64_t n = 1ull << log_n;
+#if !defined(ZK_EMU) && defined(ZK_FIELD)
+    if (want_jit) {
+        int waves = 2;
+        if (const char* e = getenv("ZK_EXPR_JIT_WAVES")) waves = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 2;
+        const std::string src = expr_jit_source<F>(words, nslots, waves);
+        ExprJitKernel* jk = src.empty() ? nullptr : expr_jit_get<F>(dc, src);
+        if (jk) {
+            const void* a_cols = base + pb;
+            const void* a_consts = base + pb + cb;
+            unsigned a_log = log_n, a_rs = rot_scale;
+            void* a_out = out;
+            void* args[] = {&a_cols, &a_consts, &a_log, &a_rs, &a_out};
+            uint64_t jb = (n + 63) / 64;
+            const uint64_t cap = (uint64_t)(dc.num_cus > 0 ? dc.num_cus : 256) * 4 * (uint64_t)waves * 4;
+            if (jb > cap) jb = cap;
+            HIP_TRY(hipModuleLaunchKernel(jk->fn, (unsigned)jb, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+            return ZK_OK;
+        }
+        // could not be built: the interpreter needs the program for ITS slot count
+        ZK_TRY(expr_compile29<F>(prog, n_ops, n_cols, cols, n_consts, words, depth, EXPR29_SLOTS));
+        HIP_TRY(hipMemcpyAsync(base, words.data(), sizeof(uint64_t) * words.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+#endif
     uint64_t blocks = (n + EXPR29_WG - 1) / EXPR29_WG;
     if (blocks > 16384) blocks = 16384;
     const size_t shmem = (size_t)(depth ? depth : 1) * F29<F>::L * EXPR29_WG * sizeof(uint32_t);

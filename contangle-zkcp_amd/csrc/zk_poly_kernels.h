@@ -619,6 +619,7 @@ __global__ void __launch_bounds__(EXPR_WG) expr_eval_kernel(const uint64_t* __re
 // One wave per workgroup (the stacks are per lane: no barrier anywhere); the LDS stack is sized by the program's depth, so
 // shallow programs get more resident waves to hide the column loads behind.
 constexpr uint32_t EXPR29_WG = 64, EXPR29_SLOTS = 2;   // (4 slots: see the note at the slot array below)
+constexpr uint32_t EXPR_JIT_SLOTS = 4, EXPR_JIT_SLOTS_MAX = 8;   // column slots of the specialised kernel (zk_poly.inl: expr_jit_source)
 enum : uint32_t { EXPR29_NORM = 7, EXPR29_REFRESH = 8, EXPR29_LOAD = 9 };
 
 template <class F>

@@ -21,7 +21,7 @@ PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo
                   "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
                   "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device", "zk_ipa_collapse_range_device", "zk_ipa_round_device",
                   "zk_poly_eval_device", "zk_poly_eval_batch_device", "zk_vec_muladd_device", "zk_vec_muladd_to_device", "zk_kate_division_device", "zk_vec_powers_device", "zk_vec_fold_many_device",
-                  "zk_ipa_fold_round_device", "zk_expr_eval_lazy_device"]
+                  "zk_ipa_fold_round_device", "zk_expr_eval_lazy_device", "zk_expr_configure"]
 
 
 def best_multiexp(coeffs, bases):
@@ -290,6 +290,7 @@ def _plib():
     lib.zk_ipa_fold_round_device.argtypes = [i32, vp, vp, vp, u64, u64, vp, vp]
     lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     lib.zk_expr_eval_lazy_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
+    lib.zk_expr_configure.argtypes = [i32]
     return lib
 
 
@@ -479,6 +480,11 @@ def evaluate_expression(field, program, columns, consts, log_n_ext, rot_scale, o
     _check(fn(field_id(field), ops, len(program), _ptr_array(columns), len(columns), _ptr(cs), len(consts), log_n_ext,
               rot_scale, _ptr(out), ctypes.c_void_p(stream)), "zk_expr_eval_lazy_device" if lazy else "zk_expr_eval_device")
     return out
+
+
+def expr_configure(jit="auto"):
+    """zk_expr_configure: the lazy evaluator's specialised (hiprtc-compiled) kernel: "auto" (2^16 rows and more), "always", "never" """
+    _check(_plib().zk_expr_configure({"auto": 0, "always": 1, "never": 2}[jit]), "zk_expr_configure")
 
 
 def to_lazy_form(field, a, stream=0):

@@ -218,6 +218,14 @@ int zk_expr_eval_lazy_device(zk_field_t f, const zk_expr_op *program_host, uint3
                              const void *consts_mont_host, uint32_t n_consts, uint32_t log_n_ext, uint32_t rot_scale, void *out_dev,
                              void *hip_stream);
 
+/* A gate expression is fixed per proving key: for evaluations of 2^16 rows and more zk_expr_eval_lazy_device writes the annotated
+ * program out as straight-line HIP (the stack resolved at generation time: no interpreter, no LDS), compiles it once per
+ * (program, device) with hiprtc -- ~10 s for the reference circuit's 268 operations; the headers it includes ship next to the
+ * library (csrc/, or $ZKCP_AMD_CSRC) -- and runs that: about half the instructions per row.  Same operations, same carry steps,
+ * same results.  jit_mode: 0 = that rule (default), 1 = always, 2 = never (the interpreter kernel).  If the specialised kernel
+ * cannot be built the interpreter runs. */
+int zk_expr_configure(int jit_mode);
+
 #ifdef __cplusplus
 }
 #endif

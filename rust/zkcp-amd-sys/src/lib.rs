@@ -265,6 +265,8 @@ extern "C" {
     pub fn zk_expr_eval_lazy_device(f: c_int, program_host: *const zk_expr_op, n_ops: u32, columns_dev: *const *const c_void, n_columns: u32,
                                consts_mont_host: *const c_void, n_consts: u32, log_n_ext: u32, rot_scale: u32, out_dev: *mut c_void,
                                hip_stream: *mut c_void) -> c_int;
+    /// 0 = the quotient kernel specialised per program (hiprtc) for evaluations of 2^16 rows and more, 1 = always, 2 = never
+    pub fn zk_expr_configure(jit_mode: c_int) -> c_int;
 }
 
 // =====================================================================================================================

@@ -1112,9 +1112,11 @@ def check_expression(zk, name, k, ext=2, seed=21):
     assert (to_host(zk, out) == _monts(name, exp)).all(), (name, k)
     # the lazy-limb evaluator: columns in the R' = 2^261 radix (times 2^5), constants and output in the usual form
     lazy_cols = [zk.halo2.to_lazy_form(name, to_device(zk, c)) for c in cols]
-    out2 = to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
-    zk.halo2.evaluate_expression(name, prog, lazy_cols, _monts(name, consts), ek, scale, out2, lazy=True)
-    assert (to_host(zk, out2) == _monts(name, exp)).all(), (name, k, "lazy limbs")
+    for mode in ("never", "always"):      # the interpreter kernel / the kernel specialised for this program (hiprtc; GPU build only)
+        zk.halo2.expr_configure(mode)
+        out2 = to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
+        zk.halo2.evaluate_expression(name, prog, lazy_cols, _monts(name, consts), ek, scale, out2, lazy=True)
+        assert (to_host(zk, out2) == _monts(name, exp)).all(), (name, k, "lazy limbs", mode)
     # adversarial bounds for the host's bound walk: long chains of additions / subtractions / negations before a product, at the
     # extreme stored values (all columns p - 1, or 0)
     top = np.tile(orc.int_to_limbs(p - 1, 4), (ne, 1))       # as stored words: x R' = p - 1
@@ -1125,9 +1127,12 @@ def check_expression(zk, name, k, ext=2, seed=21):
         xval = (p - 1 if fill is top else 0) * pow(1 << 261, -1, p) % p      # the value x behind the stored word x R'
         icol = [[xval] * ne for _ in range(5)]
         e0 = h2.eval_program(name, chain, icol, consts, ne, scale, 0)
-        out3 = to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
-        zk.halo2.evaluate_expression(name, chain, ccols, _monts(name, consts), ek, scale, out3, lazy=True)
-        assert (to_host(zk, out3) == _monts(name, [e0])[0]).all(), (name, k, "lazy limbs at the bounds")
+        for mode in ("never", "always"):
+            zk.halo2.expr_configure(mode)
+            out3 = to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
+            zk.halo2.evaluate_expression(name, chain, ccols, _monts(name, consts), ek, scale, out3, lazy=True)
+            assert (to_host(zk, out3) == _monts(name, [e0])[0]).all(), (name, k, "lazy limbs at the bounds", mode)
+    zk.halo2.expr_configure("auto")
     for bad in ([("add",)], [a, b], [("col", 9, 0)], [("const", 7)], [a] * 9 + [("add",)] * 8):   # malformed programs are refused on the host
         try:
             zk.halo2.evaluate_expression(name, bad, [to_device(zk, c) for c in cols], _monts(name, consts), ek, scale, out)
@@ -1167,9 +1172,13 @@ def check_expression_at_size(zk, name, k, ext, n_adv=13, n_fix=8, n_inst=3, samp
     # ... and the lazy-limb evaluator on the same columns in the R' radix
     for d in d_cols:
         zk.halo2.to_lazy_form(name, d)
-    out.zero_() if hasattr(out, "zero_") else out.fill(0)
-    zk.halo2.evaluate_expression(name, prog, d_cols, consts, ek, scale, out, lazy=True)
-    assert (to_host(zk, out) == got).all(), (name, k, ext, "lazy limbs differ from the saturated evaluator")
+    # ... by the interpreter kernel and by the kernel specialised for this program (hiprtc; the CPU emulator has only the former)
+    for mode in ("never", "always"):
+        zk.halo2.expr_configure(mode)
+        out.zero_() if hasattr(out, "zero_") else out.fill(0)
+        zk.halo2.evaluate_expression(name, prog, d_cols, consts, ek, scale, out, lazy=True)
+        assert (to_host(zk, out) == got).all(), (name, k, ext, "lazy limbs differ from the saturated evaluator", mode)
+    zk.halo2.expr_configure("auto")
     rng = pyref.Rng(seed)
     rows = sorted({0, 1, scale - 1, scale, scale + 1, ne - 1, ne - 2, ne - scale, ne - scale - 1, ne // 2, ne // 2 - 1}
                   | {rng.below(ne) for _ in range(samples)})
