@@ -711,7 +711,9 @@ int expr_eval_lazy_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, co
 #if !defined(ZK_EMU) && defined(ZK_FIELD)
     want_jit = g.expr_jit == 1 || (g.expr_jit == 0 && log_n >= 16);
 #endif
-    const uint32_t nslots = want_jit ? EXPR_JIT_SLOTS : EXPR29_SLOTS;
+    uint32_t nslots = want_jit ? EXPR_JIT_SLOTS : EXPR29_SLOTS;
+    if (want_jit)
+        if (const char* e = getenv("ZK_EXPR_JIT_SLOTS")) nslots = atoi(e) >= 1 && atoi(e) <= (int)EXPR_JIT_SLOTS_MAX ? (uint32_t)atoi(e) : nslots;   // (tuning)
     ZK_TRY(expr_compile29<F>(prog, n_ops, n_cols, cols, n_consts, words, depth, nslots));
     if (getenv("ZK_EXPR_STATS")) {     // (diagnostic) the executed program by opcode: what the bound walk added to the caller's ops
         uint32_t cnt[16] = {0};
