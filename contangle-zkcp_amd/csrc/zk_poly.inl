@@ -662,7 +662,9 @@ inline std::string expr_jit_include_dir() {
 // the compiled kernel of (source, device), built on first use; nullptr when it cannot be built (the caller interprets instead)
 template <class F>
 ExprJitKernel* expr_jit_get(DeviceCtx& dc, const std::string& src) {
-    static std::map<std::pair<int, std::string>, ExprJitKernel> cache;      // (called with dc.mu held; one cache per field unit)
+    static std::map<std::pair<int, std::string>, ExprJitKernel> cache;      // one cache per field unit
+    static std::mutex cache_mu;                                             // (dc.mu is per device: two devices' callers may meet here)
+    std::lock_guard<std::mutex> lk(cache_mu);
     auto key = std::make_pair(dc.device, src);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second.failed ? nullptr : &it->second;
