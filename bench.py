@@ -125,6 +125,9 @@ def setup():
                     help="single-GPU A/B: the MSMs use ONE bucket set over a table of window multiples of the bases (zk_bases_precompute, 16 x the "
                          "key in HBM) instead of one bucket set per window")
     ap.add_argument("--ntt-limbs", type=int, default=0, choices=[0, 32], help="0: lazy 29-bit limbs inside the NTT tiles (default); 32: saturated words (A/B)")
+    ap.add_argument("--expr-kernel", default="auto", choices=["auto", "never", "always"],
+                    help="halo2 work-list, lazy quotient evaluator: auto = the kernel compiled for the expression (hiprtc, first call) for 2^16 rows "
+                         "and more; never = the interpreter kernel (A/B)")
     ap.add_argument("--expr-limbs", type=int, default=0, choices=[0, 32],
                     help="halo2 work-list, quotient expression: 0 = lazy 29-bit limbs over cosets written in the R' radix (default); 32 = the saturated evaluator (A/B)")
     args = ap.parse_args()
@@ -395,6 +398,7 @@ def bench_halo2(e):
     d_S, d_W = torch.zeros((2, n, 4), dtype=torch.int64, device="cuda"), newbuf(n)    # IPA scalar / weight buffers, reused every step
     prog = e.synth.quotient_program(NCOL, N_FIXED, N_INST)
     lazy_expr = a.expr_limbs != 32
+    H.expr_configure(a.expr_kernel)
     if lazy_expr:                                     # key material in the evaluator's radix, once
         for d in d_fixed_cos:
             H.to_lazy_form(sfield, d.view(PL * m, 4), stream=e.st)
@@ -653,6 +657,8 @@ def bench_halo2(e):
                           "ntt_2p%d_per_step" % k: n_chain, "ntt_2p%d_per_step" % (ext - (QP.bit_length() - 1)): (n_chain + 1) * QP, "kate_divisions_per_step": n_kate, "evaluations_per_step": n_eval,
                           "extended_coset_parts": QP,
                           "streams": "one (serial)" if a.serial else "MSM batches on two library streams + NTT chains on a third",
+                          "quotient_kernel": ("saturated interpreter" if not lazy_expr else "lazy limbs, interpreter" if a.expr_kernel == "never"
+                                              else "lazy limbs, compiled for this expression (hiprtc, inside the first warm-up step)"),
                           "not_in_list": "RNG (blinding, random polynomials), transcript, the lookup argument's sort (CPU)"})
         if e.world > 1:
             line["config"]["parallelism"] = ("msm-window-shard x%d + all_gather ; extended coset in %d sub-cosets dealt round-robin: expression, inverse transform and "

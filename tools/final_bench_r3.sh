@@ -7,6 +7,7 @@ cd $R
 python bench.py > $O/bench_halo2.json 2> $O/bench_halo2.err
 python bench.py --serial --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_halo2_serial.json
 python bench.py --expr-limbs 32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_halo2_expr32.json
+python bench.py --expr-kernel never --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_halo2_expr_interpreter.json
 python bench.py --ipa virtual --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_halo2_ipa_virtual.json
 python bench.py --ipa fold --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_halo2_ipa_fold.json
 python bench.py --workload column 2>/dev/null | tail -1 > $O/bench_column_vesta.json
