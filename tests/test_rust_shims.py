@@ -158,6 +158,7 @@ def test_patch_files_cite_their_upstream_targets():
                         ("patches/halo2_proofs-0.2/src/arithmetic.rs", "halo2_proofs 0.2.0"),
                         ("patches/halo2_proofs-0.2/src/poly/domain.rs", "halo2_proofs 0.2.0"),
                         ("patches/halo2_proofs-0.2/src/poly/multiopen/prover.rs", "halo2_proofs 0.2.0"),
-                        ("patches/halo2_proofs-0.2/src/poly/commitment/prover.rs", "halo2_proofs 0.2.0")):
+                        ("patches/halo2_proofs-0.2/src/poly/commitment/prover.rs", "halo2_proofs 0.2.0"),
+                        ("patches/halo2_proofs-0.2/src/plonk/vanishing/prover.rs", "halo2_proofs 0.2.0")):
         src = open(os.path.join(ROOT, "rust", rel)).read()
         assert needle in src and "NOT COMPILED" in src, rel
