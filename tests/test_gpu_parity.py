@@ -547,8 +547,10 @@ def test_halo2_ipa(zk, cname, k):
     ps.check_ipa(zk, cname, k)
 
 
-def test_halo2_expression(zk):
-    ps.check_expression(zk, "PallasFp", 8, ext=3)
+@pytest.mark.parametrize("name,k,ext", [("PallasFp", 8, 3), ("PallasFq", 6, 3), ("Bn254Fr", 6, 2), ("Bls381Fr", 5, 2)])
+def test_halo2_expression(zk, name, k, ext):
+    """saturated interpreter, lazy-limb interpreter and the kernel compiled for the program (one hiprtc build per field unit)"""
+    ps.check_expression(zk, name, k, ext=ext)
 
 
 def test_halo2_expression_2p23(zk):
