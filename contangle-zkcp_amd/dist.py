@@ -126,7 +126,8 @@ def gather_stack(local, out, group=None):
             out[0].copy_(local)
         return out
     if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), group=group)
+        # (a private copy of the share: `local` may be a slice of `out`, and an aliased send / receive pair is not something to rely on)
+        dist.all_gather_into_tensor(out.view(-1), local.reshape(-1).clone(), group=group)
     else:
         t = local.cpu()
         outs = [torch.empty_like(t) for _ in range(world)]
