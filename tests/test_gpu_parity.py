@@ -394,6 +394,29 @@ def test_halo2_extended_domain_2p23(zk):
     torch.cuda.synchronize()
     got = d.cpu().numpy().view(np.uint64)
     assert (got == exp).all()
+    # the same transform stored sub-coset by sub-coset (ZK_NTT_OUT_SUBCOSETS) and every sub-coset as its own transform of size 2^20,
+    # out of place from the coefficients (what the sharded quotient and a rank of an 8-GPU run use), in both output radices
+    dom = zk.halo2.EvaluationDomain(name, 9, k)
+    d_co = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    d2 = torch.empty((ne, 4), dtype=torch.int64, device="cuda")
+    d_nat = torch.empty((ne, 4), dtype=torch.int64, device="cuda")
+    dom.coeff_to_extended(d_nat, coeffs=d_co)                      # halo2's own shift (ZETA), natural order
+    for lazy in (False, True):
+        if lazy:
+            zk.halo2.to_lazy_form(name, d_nat)
+        d2.fill_(-1)
+        dom.coeff_to_extended(d2, coeffs=d_co, parts=8, lazy_out=lazy)
+        assert bool((d2.view(8, n, 4) == d_nat.view(n, 8, 4).permute(1, 0, 2)).all()), ("parts=8", lazy)
+        for part in (0, 5):
+            d_pt = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+            dom.coeff_to_extended_part(d_co, d_pt, part, 8, lazy_out=lazy)
+            assert bool((d_pt == d_nat.view(n, 8, 4)[:, part]).all()), ("part", part, lazy)
+    # ... and back: part_to_coeff of a sub-coset's values of a polynomial of degree < n returns its coefficients
+    d_pt = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    dom.coeff_to_extended_part(d_co, d_pt, 3, 8)
+    dom.part_to_coeff(d_pt, 3, 8)
+    assert bool((d_pt == d_co).all())
+    del d2, d_nat, d_pt
     # extended_to_coeff: inverse transform + coset un-shift brings the padded coefficients back
     winv, ginv = orc.fe_op(name, "inv", w_ext), orc.fe_op(name, "inv", g)
     zk.ntt(name, d, winv, scale_by_n_inv=True, coset_post=ginv)
