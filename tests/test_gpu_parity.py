@@ -431,6 +431,42 @@ def test_halo2_extended_domain_2p23(zk):
     assert (d.cpu().numpy().view(np.uint64) == orc.ark_fft(name, dense, "coset_ifft", threads=os.cpu_count() or 8)).all()
 
 
+def test_quotient_by_parts_2p23(zk):
+    """configs[2] at its own shape: a quotient of 2^23 extended values through its 8 sub-cosets (part_to_coeff + the mixing scalars)
+    equals extended_to_coeff coefficient for coefficient (device-side comparison of all 2^23), and the combination of the sub-cosets'
+    commitments equals the commitments of the pieces (2^20-point MSMs)"""
+    import torch
+    name, cname, k, parts = "PallasFp", "Vesta", 20, 8
+    dom = zk.halo2.EvaluationDomain(name, 9, k)
+    n, ne, p = dom.n, dom.extended_len(), dom._p
+    h_ext = torch.from_numpy(ps.rand_field(name, ne, 0x51DE).view(np.int64)).cuda()
+    direct = h_ext.clone()
+    dom.extended_to_coeff(direct)                                              # upstream's path: [8 pieces, n]
+    A = h_ext.view(n, parts, 4).permute(1, 0, 2).contiguous()                  # sub-coset j = the extended values i * 8 + j
+    for j in range(parts):
+        dom.part_to_coeff(A[j], j, parts)
+    c = dom.part_mix(parts)
+    mont = lambda v: zk.halo2._mont_limbs(v % p, p)
+    acc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    for i in range(parts):                                                     # h^(i) = sum_j c[i][j] A_j, on the device
+        acc.copy_(A[0])
+        zk.vec_op(name, "scale", acc, scalar=mont(c[i][0]))
+        for j in range(1, parts):
+            zk.halo2.vec_muladd(name, A[j], acc, mont(c[i][j]), out=acc)
+        assert bool((acc == direct.view(parts, n, 4)[i]).all()), ("piece", i)
+    # commitments: linear in the folded coefficients
+    pts = ps.bases_for(cname, n)
+    bases = zk.Bases(cname, pts)
+    C = zk.msm_batch(bases, A, montgomery=True)
+    rows = dom.piece_scalars(parts)
+    got = zk.halo2.combine_commitments(cname, list(C), [[(j, sc) for j, s_, sc in terms] for _, terms in rows[:3]],
+                                       to_device=lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).cuda())
+    exp = zk.msm_batch(bases, direct.view(parts, n, 4)[:3].contiguous(), montgomery=True)
+    for q in range(3):
+        assert (zk.point_to_affine(cname, got[q]) == zk.point_to_affine(cname, exp[q])).all(), ("commitment", q)
+    bases.free()
+
+
 def test_groth16_bn254_2p22(zk):
     """configs[3]: BN254 Fr at the 2^22 domain: the NTT and the whole witness map (7 NTTs + glue) vs the oracle"""
     thr = os.cpu_count() or 8
