@@ -612,6 +612,35 @@ def test_halo2_expression(zk, name, k, ext):
     ps.check_expression(zk, name, k, ext=ext)
 
 
+def test_halo2_expression_kernel_falls_back_to_the_interpreter(zk):
+    """the compiled quotient kernel needs the field headers next to the library: when they cannot be found the hiprtc build fails and
+    the interpreter kernel runs instead -- same results (a program no other test uses: a failed build is remembered per program)"""
+    name, k = "PallasFp", 7
+    ne = 1 << k
+    cols = [ps.rand_field(name, ne, 0xFA11 + c) for c in range(3)]
+    consts = ps.rand_field(name, 2, 0xFA20)
+    a, b, c = (("col", i, 0) for i in range(3))
+    prog = [a, b, ("mul",), c, ("scale", 1), ("sub",), ("col", 0, 2), ("mul",), ("const", 0), ("add",), b, ("neg",), ("mul",)]
+    d_cols = [ps.to_device(zk, x) for x in cols]
+    ref = ps.to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
+    zk.halo2.evaluate_expression(name, prog, d_cols, consts, k, 1, ref)
+    for d in d_cols:
+        zk.halo2.to_lazy_form(name, d)
+    saved = os.environ.get("ZKCP_AMD_CSRC")
+    os.environ["ZKCP_AMD_CSRC"] = "/nonexistent/csrc"
+    try:
+        zk.halo2.expr_configure("always")
+        out = ps.to_device(zk, np.zeros((ne, 4), dtype=np.uint64))
+        zk.halo2.evaluate_expression(name, prog, d_cols, consts, k, 1, out, lazy=True)
+        assert (ps.to_host(zk, out) == ps.to_host(zk, ref)).all()
+    finally:
+        zk.halo2.expr_configure("auto")
+        if saved is None:
+            del os.environ["ZKCP_AMD_CSRC"]
+        else:
+            os.environ["ZKCP_AMD_CSRC"] = saved
+
+
 def test_halo2_expression_2p23(zk):
     """configs[2] at its own shape: the bench's 268-op quotient program over 30 columns of 2^23 extended rows (k = 20, degree 9),
     sampled rows (incl. the rows whose rotations wrap) against Python integers"""
