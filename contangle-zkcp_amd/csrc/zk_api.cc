@@ -1552,6 +1552,22 @@ API int zk_expr_eval_lazy_device(zk_field_t f, const zk_expr_op* prog, uint32_t 
     return ZK_ERR_INVALID_ARG;
 }
 
+API int zk_expr_specialised_source(zk_field_t f, const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, uint32_t n_consts, char* out, uint64_t cap,
+                                   uint64_t* len_out) {
+    if (!prog || !len_out) return ZK_ERR_INVALID_ARG;
+    std::string src;
+    int st = ZK_ERR_INVALID_ARG;
+    FIELD_SWITCH(f, st = expr_source_run<F>(prog, n_ops, n_cols, n_consts, src));
+    ZK_TRY(st);
+    *len_out = src.size();
+    if (out && cap) {
+        const size_t k = src.size() < cap - 1 ? src.size() : (size_t)cap - 1;
+        memcpy(out, src.data(), k);
+        out[k] = 0;
+    }
+    return ZK_OK;
+}
+
 API int zk_expr_configure(int jit_mode) {
     if (jit_mode < 0 || jit_mode > 2) return ZK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(g.mu);

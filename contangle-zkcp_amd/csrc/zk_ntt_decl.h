@@ -2,6 +2,7 @@
 // zk_ntt_inst.cc.  Kept apart from zk_internal.h so that adding a field-side entry point does not rebuild the
 // (slow) curve units.
 #pragma once
+#include <string>
 #include "zk_internal.h"
 #include "zkcp_amd_prover.h"
 namespace zk {
@@ -60,6 +61,8 @@ int ipa_update_weights_run(Fe<F>* W, uint64_t m0, uint64_t bit, const Fe<F>& u, 
 template <class F>
 int expr_eval_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const Fe<F>* consts,
                   uint32_t n_consts, uint32_t log_n, uint32_t rot_scale, Fe<F>* out, hipStream_t st);
+template <class F>
+int expr_source_run(const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, uint32_t n_consts, std::string& out);
 template <class F>
 int expr_eval_lazy_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const Fe<F>* consts,
                        uint32_t n_consts, uint32_t log_n, uint32_t rot_scale, Fe<F>* out, hipStream_t st);

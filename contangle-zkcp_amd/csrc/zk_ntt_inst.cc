@@ -27,6 +27,7 @@ template int expr_eval_run<ZK_FIELD>(DeviceCtx&, const zk_expr_op*, uint32_t, co
                                      Fe<ZK_FIELD>*, hipStream_t);
 template int expr_eval_lazy_run<ZK_FIELD>(DeviceCtx&, const zk_expr_op*, uint32_t, const void* const*, uint32_t, const Fe<ZK_FIELD>*, uint32_t, uint32_t, uint32_t,
                                           Fe<ZK_FIELD>*, hipStream_t);
+template int expr_source_run<ZK_FIELD>(const zk_expr_op*, uint32_t, uint32_t, uint32_t, std::string&);
 template int r1cs_matvec_run<ZK_FIELD>(const R1csMatrix&, const Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, uint64_t, hipStream_t);
 template int witness_map_run<ZK_FIELD>(DeviceCtx&, int, Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, Fe<ZK_FIELD>*, uint32_t, hipStream_t);
 }  // namespace zk

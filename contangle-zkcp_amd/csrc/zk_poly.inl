@@ -700,6 +700,23 @@ ExprJitKernel* expr_jit_get(DeviceCtx& dc, const std::string& src) {
 }
 #endif
 
+// the source of the specialised kernel for a program, without a device (zk_expr_specialised_source: diagnostics, the CPU test tier)
+template <class F>
+int expr_source_run(const zk_expr_op* prog, uint32_t n_ops, uint32_t n_cols, uint32_t n_consts, std::string& out) {
+#if !defined(ZK_EMU) && defined(ZK_FIELD)
+    if (n_ops == 0 || n_ops > EXPR_MAX_OPS || n_cols > EXPR_MAX_COLS || n_consts > EXPR_MAX_CONSTS) return ZK_ERR_INVALID_ARG;
+    std::vector<const void*> cols(n_cols ? n_cols : 1, (const void*)&out);      // (the walk only asks that a column be present)
+    std::vector<uint64_t> words;
+    uint32_t depth = 0;
+    ZK_TRY(expr_compile29<F>(prog, n_ops, n_cols, cols.data(), n_consts, words, depth, EXPR_JIT_SLOTS));
+    out = expr_jit_source<F>(words, EXPR_JIT_SLOTS, 2);
+    return out.empty() ? ZK_ERR_INVALID_ARG : ZK_OK;
+#else
+    (void)prog, (void)n_ops, (void)n_cols, (void)n_consts, (void)out;
+    return ZK_ERR_UNSUPPORTED;
+#endif
+}
+
 // columns: x R' mod p (R' = 2^261), canonical words; constants: standard Montgomery on the host (converted here); out: standard
 template <class F>
 int expr_eval_lazy_run(DeviceCtx& dc, const zk_expr_op* prog, uint32_t n_ops, const void* const* cols, uint32_t n_cols, const Fe<F>* consts,

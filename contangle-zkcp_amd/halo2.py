@@ -21,7 +21,7 @@ PROVER_EXPORTS = ["zk_batch_invert_device", "zk_prefix_product_device", "zk_halo
                   "zk_halo2_lookup_product_device", "zk_inner_product_device", "zk_vec_fold_device", "zk_ipa_fold_bases_device",
                   "zk_expr_eval_device", "zk_ipa_virtual_scalars_device", "zk_ipa_update_weights_device", "zk_ipa_collapse_device", "zk_ipa_collapse_range_device", "zk_ipa_round_device",
                   "zk_poly_eval_device", "zk_poly_eval_batch_device", "zk_vec_muladd_device", "zk_vec_muladd_to_device", "zk_kate_division_device", "zk_vec_powers_device", "zk_vec_fold_many_device",
-                  "zk_ipa_fold_round_device", "zk_expr_eval_lazy_device", "zk_expr_configure"]
+                  "zk_ipa_fold_round_device", "zk_expr_eval_lazy_device", "zk_expr_configure", "zk_expr_specialised_source"]
 
 
 def best_multiexp(coeffs, bases):
@@ -291,6 +291,7 @@ def _plib():
     lib.zk_expr_eval_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     lib.zk_expr_eval_lazy_device.argtypes = [i32, ctypes.POINTER(ExprOp), u32, pp, u32, vp, u32, u32, u32, vp, vp]
     lib.zk_expr_configure.argtypes = [i32]
+    lib.zk_expr_specialised_source.argtypes = [i32, ctypes.POINTER(ExprOp), u32, u32, u32, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
     return lib
 
 
@@ -485,6 +486,21 @@ def evaluate_expression(field, program, columns, consts, log_n_ext, rot_scale, o
 def expr_configure(jit="auto"):
     """zk_expr_configure: the lazy evaluator's specialised (hiprtc-compiled) kernel: "auto" (2^16 rows and more), "always", "never" """
     _check(_plib().zk_expr_configure({"auto": 0, "always": 1, "never": 2}[jit]), "zk_expr_configure")
+
+
+def expr_specialised_source(field, program, n_columns, n_consts):
+    """the HIP source of the kernel zk_expr_eval_lazy_device compiles for `program` (no device needed)"""
+    ops = (ExprOp * len(program))()
+    for i, o in enumerate(program):
+        ops[i].op = EXPR_CODES[o[0]]
+        ops[i].rot = int(o[2]) if o[0] == "col" and len(o) > 2 else 0
+        ops[i].arg = int(o[1]) if len(o) > 1 else 0
+    n = ctypes.c_uint64(0)
+    fid = field_id(field)
+    _check(_plib().zk_expr_specialised_source(fid, ops, len(program), n_columns, n_consts, None, 0, ctypes.byref(n)), "zk_expr_specialised_source")
+    buf = ctypes.create_string_buffer(n.value + 1)
+    _check(_plib().zk_expr_specialised_source(fid, ops, len(program), n_columns, n_consts, buf, n.value + 1, ctypes.byref(n)), "zk_expr_specialised_source")
+    return buf.value.decode()
 
 
 def to_lazy_form(field, a, stream=0):

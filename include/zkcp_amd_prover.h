@@ -225,6 +225,10 @@ int zk_expr_eval_lazy_device(zk_field_t f, const zk_expr_op *program_host, uint3
  * same results.  jit_mode: 0 = that rule (default), 1 = always, 2 = never (the interpreter kernel).  If the specialised kernel
  * cannot be built the interpreter runs. */
 int zk_expr_configure(int jit_mode);
+/* The HIP source zk_expr_eval_lazy_device would compile for this program (no device needed: diagnostics, and the CPU test tier
+ * cross-compiles it).  *len_out = its length; at most cap - 1 bytes and a terminating 0 are written to out (out may be NULL). */
+int zk_expr_specialised_source(zk_field_t f, const zk_expr_op *program_host, uint32_t n_ops, uint32_t n_columns, uint32_t n_consts, char *out,
+                               uint64_t cap, uint64_t *len_out);
 
 #ifdef __cplusplus
 }

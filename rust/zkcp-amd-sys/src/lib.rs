@@ -267,6 +267,8 @@ extern "C" {
                                hip_stream: *mut c_void) -> c_int;
     /// 0 = the quotient kernel specialised per program (hiprtc) for evaluations of 2^16 rows and more, 1 = always, 2 = never
     pub fn zk_expr_configure(jit_mode: c_int) -> c_int;
+    pub fn zk_expr_specialised_source(f: c_int, program_host: *const zk_expr_op, n_ops: u32, n_columns: u32, n_consts: u32, out: *mut c_char, cap: u64,
+                                      len_out: *mut u64) -> c_int;
 }
 
 // =====================================================================================================================
