@@ -6,16 +6,19 @@ the configuration `metric` is quoted on), inputs resident in HBM, through the C 
       reference's ElGamalGadget (13 advice, 8 fixed, a lookup, equality over 16 columns, degree-9 gates;
       circuits-halo2/src/encryption.rs:83-161; SURVEY 8a a11 / 8d "Config 3"), in upstream's order -- see bench_halo2():
       advice commits + NTT chains, lookup and permutation grand products with their commits and chains, the quotient
-      (expression evaluation on the extended coset, division by the vanishing polynomial, extended_to_coeff, 8 h-piece
-      commits), the evaluations at x and its rotations with their multiopen folds, and the k-round inner-product argument.  NTT
+      (expression evaluation on the extended coset -- in a kernel compiled for that expression on first use --, division by the
+      vanishing polynomial, extended_to_coeff, 8 h-piece commits), the evaluations at x and its rotations with their multiopen folds, and the k-round inner-product argument.  NTT
       chains run on a second HIP stream beside the batched MSMs.  RNG, transcript and the lookup's sort stay on the CPU.
   metric    = constraints/sec = rows / wall-clock of the timed region (whole job)
   --workload column : BASELINE configs[1], one 2^20 MSM + one 2^20 NTT per step (the microbench; prints msm_mops)
   --workload groth16: the GPU work of one Groth16 proof at domain 2^logn (SURVEY 8d "Config 4")
-  N > 1     = every MSM of 2^17 points or more is window-range sharded over the N ranks (one process per GPU) and combined with
-              one all_gather of Jacobian points over RCCL (contangle-zkcp_amd/dist.py), the IPA's generator collapse by output
-              range; NTT chains, the quotient expression and the small IPA rounds run on every rank.  Total work per step is
-              fixed -> "scaling": "strong".
+  N > 1     = every MSM of 2^17 points or more is sharded over the N ranks (one process per GPU): a single MSM by scalar-window range,
+              a batch with at least one vector per rank by vector; one all_gather of Jacobian points over RCCL either way
+              (contangle-zkcp_amd/dist.py).  The quotient AND its commitments are sharded by sub-coset of the extended domain (8 sub-cosets
+              dealt round-robin: expression, division, an inverse transform of size 2^20 and the MSM of the result per sub-coset; the
+              ranks exchange 8 commitments and one folded vector each, never h), the IPA's generator collapse by output range.  The
+              size-2^20 transforms, the grand products and the small IPA rounds run on every rank.  Total work per step is fixed ->
+              "scaling": "strong".  `digest` in the line is the same for every N and every order of work.
 
 Launch: `python bench.py [--gpus 1 --steps K --warmup W]`, or for N > 1
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`.
